@@ -1,0 +1,72 @@
+/*
+ * nnl.h — C ABI of libnnl_hip.so: the MI355X (gfx950) kernels behind the Learner.fit() hot path.
+ *
+ * The reference (NickTravers/NeuralNetworkLibrary) has NO FFI / plugin registry: every FLOP is an
+ * eager torch op called from its nn.Modules.  The drop-in boundary is therefore
+ * the set of torch call sites on the hot path; each entry point below names the reference call site
+ * (file:line, relative to the reference root) whose arithmetic it replaces.  The Python host side
+ * (neuralnetworklibrary_amd/ops.py) binds these with ctypes and calls them from
+ * torch.autograd.Function.forward/backward — see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers unless stated.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*); no implicit device sync.
+ *  - the library never allocates/frees device memory and keeps no pointer past return; workspaces are
+ *    caller-owned, sized by the matching *_workspace_bytes().
+ *  - return 0 on success, negative nnl_status_t on failure; nnl_last_error() gives the text
+ *    (thread-local).  No C++ exception crosses the ABI.
+ *  - fp32 everywhere (the reference is fp32, README.md:19-24); indices are int64 (torch LongTensor).
+ *  - activations are NHWC ("channels_last" physical layout of a logical NCHW torch tensor);
+ *    conv filters are KRSC (= channels_last physical layout of a logical [K,C,R,S] parameter).
+ */
+#ifndef NNL_H_
+#define NNL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  NNL_OK = 0,
+  NNL_ERR_INVALID_ARG = -1,
+  NNL_ERR_HIP = -2,
+  NNL_ERR_UNSUPPORTED = -3,
+  NNL_ERR_WORKSPACE = -4
+} nnl_status_t;
+
+int nnl_version(void);
+const char* nnl_last_error(void);
+
+/* ---- profiling hooks (bench.py roofline leg): HIP events recorded on the launch stream --------- */
+enum { NNL_PROF_CONV_FWD = 0, NNL_PROF_CONV_DGRAD = 1, NNL_PROF_CONV_WGRAD = 2, NNL_PROF_EMBDOT = 3,
+       NNL_PROF_TABULAR = 4, NNL_PROF_RETINA_LOSS = 5, NNL_PROF_LSTM = 6, NNL_PROF_SOFTMAX_CE = 7,
+       NNL_PROF_ELEMENTWISE = 8, NNL_PROF_GEMM = 9, NNL_PROF_OPTIM = 10, NNL_PROF_KINDS = 11 };
+/* enable!=0 starts recording (bounded event pool); 0 stops. */
+int nnl_prof_enable(int enable);
+/* Synchronises the recorded events and returns, per kind: launches, total ms, total algorithmic work
+ * (flops or bytes as documented per op).  Arrays have NNL_PROF_KINDS entries. Resets the pool. */
+int nnl_prof_collect(int64_t* launches, double* total_ms, double* total_work);
+
+/* ---- K4: EmbeddingDotBias (CollabFilterNet.forward, Applications/CollabFiltering.py:196-204) ----
+ * y_b = lo + (hi-lo)*sigmoid( sum_d U[x[b,0],d]*M[x[b,1],d] + bu[x[b,0]] + bi[x[b,1]] )   (has_range!=0)
+ * y_b =                         sum_d ...                + bu + bi                       (has_range==0)
+ * x: int64 [n,2]; U [n_user,D]; M [n_item,D]; bu [n_user]; bi [n_item]; y [n]; z [n] (pre-activation,
+ * saved for backward; may be NULL).  Out-of-range indices are reported through *err_flag (device int32,
+ * may be NULL; set to 1) and the sample is skipped — torch raises IndexError at the same place. */
+int nnl_embdotbias_fwd(const int64_t* x, const float* U, const float* M, const float* bu, const float* bi,
+                       float* y, float* z, int64_t n, int64_t n_user, int64_t n_item, int64_t D,
+                       int has_range, float lo, float hi, int32_t* err_flag, void* stream);
+/* Backward of the above = the four dense embedding_backward scatter-adds + sigmoid/mul backward
+ * (autograd of CollabFiltering.py:198-203).  dU/dM/dbu/dbi are DENSE tables (nn.Embedding sparse=False,
+ * General/Layers.py:59) which this call first zero-fills, then scatter-adds into. */
+int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float* M, const float* z, const float* dy,
+                       float* dU, float* dM, float* dbu, float* dbi, int64_t n, int64_t n_user,
+                       int64_t n_item, int64_t D, int has_range, float lo, float hi, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNL_H_ */

@@ -1,0 +1,607 @@
+"""`Learner` — the training / evaluation loop of the drop-in API.
+
+Mirror of the reference's General/Learner.py (class Learner :64-887): same constructor, same public
+methods and keyword arguments, same numerical behaviour of the loop, including its quirks:
+  * a full validation pass before epoch 0 sets `min_loss` (Learner.py:566);
+  * last-batch learning-rate scaling `lr * bs / data.bs` (Learner.py:503-505);
+  * EMA of the minibatch loss with constants .98/.02 and debiasing `/(1-.98^(i+1))` (Learner.py:610-611);
+  * `model.reset()` is never called between train and val (Learner.py:346,417,587,839);
+  * early stop when val_loss > 20*min_loss (Learner.py:672-675); find_lr break_fac (Learner.py:866);
+  * `get_sched` converts only `start_val` from list to array (the `end_value` typo, Learner.py:716).
+What is new (MI355X-first, not in the reference):
+  * device-agnostic placement through Core.default_device() instead of hard `.cuda()` (Learner.py:107);
+  * one-process-per-GPU data parallelism: when torch.distributed is initialised, gradients are
+    all-reduced over RCCL by `neuralnetworklibrary_amd.dist.GradSync` (attached to the Optimizer), the
+    last-batch lr scale uses the GLOBAL batch size, evaluation sums are all-reduced, and only rank 0
+    prints / saves;
+  * plotting is imported lazily (matplotlib is UI, out of scope for the hot path).
+"""
+import copy
+import os
+import time
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.optim as optim
+
+from .Core import (ARR, bn_types, combine_models, correct_foldername, default_device, linear_space, list_mult,
+                   outer_mult, to_cuda)
+from .LossesMetrics import AUC
+from .Optimizer import Optimizer, get_param_dict
+
+__all__ = ['Learner', 'end_metrics', 'SGD_Mom', 'Adam2', 'opt_dict', 'loss_func_dict', 'plot_confusion_matrix']
+
+# registries (General/Learner.py:16-21)
+end_metrics = {'auc': AUC}
+SGD_Mom = partial(optim.SGD, momentum=0.9)
+Adam2 = partial(optim.Adam, betas=(0.9, 0.99))
+opt_dict = {'default': SGD_Mom, 'SGD_Mom': SGD_Mom, 'SGD': optim.SGD, 'Adam': optim.Adam, 'Adam2': Adam2}
+loss_func_dict = {'cont': nn.MSELoss(), 'cat': nn.CrossEntropyLoss(), 'single_label': nn.CrossEntropyLoss(),
+                  'multi_label': nn.BCEWithLogitsLoss()}
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def _rank():
+    d = _dist()
+    return d.get_rank() if d else 0
+
+
+def _batch_size(y_batch):
+    return len(y_batch) if type(y_batch) != list else len(y_batch[0])
+
+
+def plot_confusion_matrix(cm, classes, normalize=False, title='Confusion matrix', cmap=None):
+    "Plot a confusion matrix (General/Learner.py:32-60; UI helper)."
+    import itertools
+    import matplotlib.pyplot as plt
+    if normalize:
+        cm = cm.astype('float') / cm.sum(axis=1)[:, np.newaxis]
+    print(cm)
+    plt.imshow(cm, interpolation='nearest', cmap=cmap or plt.cm.Blues)
+    plt.title(title)
+    plt.colorbar()
+    ticks = np.arange(len(classes))
+    plt.xticks(ticks, classes, rotation=45)
+    plt.yticks(ticks, classes)
+    fmt = '.2f' if normalize else 'd'
+    thresh = cm.max() / 2.
+    for i, j in itertools.product(range(cm.shape[0]), range(cm.shape[1])):
+        plt.text(j, i, format(cm[i, j], fmt), horizontalalignment="center",
+                 color="white" if cm[i, j] > thresh else "black")
+    plt.ylabel('True label')
+    plt.xlabel('Predicted label')
+    plt.tight_layout()
+
+
+class Learner(object):
+    """Model + data + optimizer + loss, with fit / fit_cycles / fit_one_cycle / find_lr / evaluate / predict
+    (General/Learner.py:64-115 for the arguments and attributes)."""
+
+    verbose = True   # print epoch tables (rank 0 only)
+
+    def __init__(self, PATH, data, model, optimizer='default', loss_func='default', use_moving_avg=True):
+        PATH = correct_foldername(PATH)
+        os.makedirs(PATH + 'models', exist_ok=True)
+        self.PATH, self.data, self.model = PATH, data, model.to(default_device())
+        self.loss_sched, self.lr_sched, self.mom_sched, self.betas_sched = [], [], [], []
+        self.moving_avg_loss, self.use_moving_avg = 0, use_moving_avg
+        self.target_type = data.target_type
+        self.loss_func = loss_func_dict[self.target_type] if loss_func == 'default' else loss_func
+        self.optimizer = Optimizer(opt_dict[optimizer], self.model) if isinstance(optimizer, str) else optimizer
+        self.bn_frozen = None
+        self.grad_sync = None
+
+    # ---- data parallelism (new) -----------------------------------------------------
+    def distribute(self, bucket_mb=25.0, sync_bn=True):
+        """Make this learner one rank of a synchronous data-parallel job (one process per GPU)."""
+        from .. import dist as nnl_dist
+        self.grad_sync = nnl_dist.GradSync(self.model, bucket_mb=bucket_mb)
+        self.optimizer.attach_grad_sync(self.grad_sync)
+        if sync_bn:
+            nnl_dist.enable_sync_bn(self.model)
+        return self
+
+    def _reattach(self):
+        if self.grad_sync is not None:
+            self.grad_sync.rebuild()
+            self.optimizer.attach_grad_sync(self.grad_sync)
+
+    def _global_bs(self, bs):
+        d = _dist()
+        if d is None:
+            return bs, self.data.bs
+        t = torch.tensor([float(bs)], device=default_device())
+        d.all_reduce(t)
+        return int(t.item()), self.data.bs * d.get_world_size()
+
+    # ---- (1) save / load (General/Learner.py:119-153) ---------------------------------------------
+    def save(self, filename, save_optimizer=False):
+        if _rank() != 0:
+            return
+        state = {'model_state': self.model.state_dict()}
+        if save_optimizer:
+            state['optimizer_state'] = self.optimizer.opt.state_dict()
+        torch.save(state, self.PATH + 'models/' + filename + '.pt')
+
+    def load(self, filename, saved_optimizer=False):
+        path = self.PATH + 'models/' + filename + '.pt'
+        if os.path.isfile(path):
+            state = torch.load(path, map_location=default_device())
+            self.model.load_state_dict(state['model_state'])
+            if saved_optimizer:
+                self.optimizer.opt.load_state_dict(state['optimizer_state'])
+        else:
+            print("no file found at '{}'".format(path))
+
+    # ---- (2) plotting (General/Learner.py:158-228; UI, lazily imports matplotlib) -------------------
+    @staticmethod
+    def smooth_timeseries(s, r):
+        """Centered moving average of radius r with shrinking windows at both ends (Learner.py:159-184)."""
+        N = len(s)
+        out = np.zeros(N)
+        for i in range(r):
+            out[i] = sum(s[0:2 * i + 1]) / (2 * i + 1)
+            out[N - 1 - i] = sum(s[N - 1 - 2 * i:N + 1]) / (2 * i + 1)
+        for i in range(r, N - r):
+            out[i] = sum(s[i - r:i + r + 1]) / (2 * r + 1)
+        return list(out)
+
+    def _default_radius(self):
+        return max(5, int(len(self.data.train_dl) / 50))
+
+    def plot_loss_sched(self, smoothing_radius='default'):
+        import matplotlib.pyplot as plt
+        r = self._default_radius() if smoothing_radius == 'default' else smoothing_radius
+        plt.plot(self.smooth_timeseries(self.loss_sched, r))
+        plt.xlabel('minibatch'); plt.ylabel('train loss')
+
+    def plot_lr_sched(self):
+        import matplotlib.pyplot as plt
+        plt.plot(self.lr_sched); plt.xlabel('minibatch'); plt.ylabel('learning rate')
+
+    def plot_mom_sched(self):
+        import matplotlib.pyplot as plt
+        plt.plot(self.mom_sched); plt.xlabel('minibatch'); plt.ylabel('momentum')
+
+    def plot_beta_sched(self):
+        import matplotlib.pyplot as plt
+        plt.plot([b1 for (b1, b2) in self.betas_sched]); plt.xlabel('minibatch'); plt.ylabel('beta_1')
+
+    def plot_lr_and_loss_sched(self, smoothing_radius='default'):
+        import matplotlib.pyplot as plt
+        r = self._default_radius() if smoothing_radius == 'default' else smoothing_radius
+        fig = plt.figure(figsize=(12, 6))
+        sp = fig.add_subplot(1, 2, 1); plt.plot(self.lr_sched); sp.set(xlabel='minibatch', ylabel='learning rate')
+        sp = fig.add_subplot(1, 2, 2); plt.plot(self.smooth_timeseries(self.loss_sched, r))
+        sp.set(xlabel='minibatch', ylabel='loss')
+
+    # ---- (3) freezing (General/Learner.py:237-272): each call rebuilds the Optimizer ----------------
+    def _new_optimizer(self):
+        self.optimizer = Optimizer(self.optimizer.opt_func, self.model)
+        self._reattach()
+
+    def freeze(self):
+        for p in self.model.parameters():
+            p.requires_grad = False
+        for p in self.model.head.parameters():
+            p.requires_grad = True
+        self._new_optimizer()
+
+    def unfreeze(self):
+        for p in self.model.parameters():
+            p.requires_grad = True
+        self._new_optimizer()
+
+    def bn_freeze(self, freeze_type='non_head'):
+        for m in self.model.modules():
+            if isinstance(m, bn_types):
+                for p in m.parameters():
+                    p.requires_grad = False
+        if freeze_type == 'non_head':
+            for m in self.model.head.modules():
+                if isinstance(m, bn_types):
+                    for p in m.parameters():
+                        p.requires_grad = True
+        self._new_optimizer()
+        self.bn_frozen = freeze_type
+
+    def bn_unfreeze(self):
+        for m in self.model.modules():
+            if isinstance(m, bn_types):
+                for p in m.parameters():
+                    p.requires_grad = True
+        self._new_optimizer()
+        self.bn_frozen = None
+
+    def _apply_bn_frozen(self):
+        """Re-freeze BN modules after model.train() (General/Learner.py:589-594, :841-846)."""
+        if self.bn_frozen in ['all', 'non_head']:
+            for m in self.model.modules():
+                if isinstance(m, bn_types):
+                    m.training = False
+        if self.bn_frozen == 'non_head':
+            for m in self.model.head.modules():
+                if isinstance(m, bn_types):
+                    m.training = True
+
+    # ---- (4) prediction / evaluation ----------------------------------------------------------------
+    def predict1minibatch(self, x_batch):
+        "model(*x) for list inputs else model(x)  (General/Learner.py:277-284)"
+        return self.model(*x_batch) if isinstance(x_batch, list) else self.model(x_batch)
+
+    def predict(self, dl, correct_probs=True, thresh=0.05, max_overlap=0.5,
+                rel_thresh=None, top_k=1000, max_boxes=20, dup=None, inc=None):
+        """Predictions for a whole dataloader, post-processed per target_type (General/Learner.py:286-393)."""
+        if self.target_type == 'bbox' and dl not in ['val', 'test']:
+            raise ValueError("Must use 'val' or 'test' dataloader for target_type = bbox.")
+        which = dl
+        if dl == 'val':
+            dl = self.data.val_dl
+        elif dl == 'test':
+            dl = self.data.test_dl
+        self.model.eval()
+        out = []
+        with torch.no_grad():
+            for j, (x_batch, y_batch) in enumerate(dl):
+                x_batch = to_cuda(x_batch)
+                y_pred = self.predict1minibatch(x_batch)
+                if isinstance(y_pred, tuple):
+                    y_pred = y_pred[0]
+                if self.target_type == 'cont':
+                    out.append(ARR(y_pred))
+                elif self.target_type in ['cat', 'single_label', 'text_classify']:
+                    probs = ARR(y_pred) if not correct_probs else ARR(F.log_softmax(y_pred, dim=1).exp())
+                    out.append([probs, probs.argmax(axis=1)])
+                elif self.target_type == 'multi_label':
+                    sig = ARR(y_pred.sigmoid())
+                    probs = sig if correct_probs else ARR(y_pred)
+                    out.append([probs, np.around(sig).astype(int)])
+                elif self.target_type == 'bbox':
+                    anchors, reg, clas = y_pred
+                    B, Cl, Sc = self.model.BBoxPredictor(x_batch, reg, clas, anchors, thresh, max_overlap,
+                                                         rel_thresh, top_k, max_boxes, dup, inc)
+                    B, Cl, Sc = B[0], Cl[0], Sc[0]          # bs = 1 for 'val' / 'test' bbox loaders
+                    ds = self.data.val_ds if which == 'val' else self.data.test_ds
+                    out.append([list_mult(B, 1 / ds.images[j]['scale']), Cl, Sc])
+        if self.target_type == 'cont':
+            return np.concatenate(out)
+        if self.target_type in ['cat', 'single_label', 'multi_label', 'text_classify']:
+            return [np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])]
+        return out
+
+    def _allreduce_sums(self, values):
+        d = _dist()
+        if d is None:
+            return values
+        t = torch.tensor(values, dtype=torch.float64, device=default_device())
+        d.all_reduce(t)
+        return t.tolist()
+
+    def evaluate(self, dataset_type, metrics=[]):
+        """Size-weighted mean loss (+ accuracy and metrics for 'val')  (General/Learner.py:395-485)."""
+        use_end = any((m in end_metrics) for m in metrics if isinstance(m, str))
+        self.model.eval()
+        total_loss, n_seen = 0., 0
+
+        if dataset_type == 'train':
+            with torch.no_grad():
+                for x_batch, y_batch in self.data.train_dl:
+                    bs = _batch_size(y_batch)
+                    x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
+                    total_loss += bs * self.loss_func(self.predict1minibatch(x_batch), y_batch).item()
+                    n_seen += bs
+            total_loss, n_seen = self._allreduce_sums([total_loss, n_seen])
+            return total_loss / n_seen
+
+        if dataset_type == 'val':
+            num_correct, Y, YPRED = 0, [], []
+            metric_values = np.zeros(len(metrics))
+            with torch.no_grad():
+                for x_batch, y_batch in self.data.val_dl:
+                    bs = _batch_size(y_batch)
+                    x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
+                    y_pred = self.predict1minibatch(x_batch)
+                    total_loss += bs * self.loss_func(y_pred, y_batch).item()
+                    n_seen += bs
+                    if use_end:
+                        YPRED.append(y_pred); Y.append(y_batch)
+                    for i, m in enumerate(metrics):
+                        if isinstance(m, str) and m in end_metrics:
+                            continue
+                        metric_values[i] += bs * m(y_pred, y_batch).item()
+                    if self.target_type in ['cat', 'single_label']:
+                        num_correct += (y_pred.max(dim=1)[1] == y_batch).sum().item()
+                    elif self.target_type == 'multi_label':
+                        num_correct += (y_pred.sigmoid().round() == y_batch).sum().item()
+            if use_end:
+                YPRED, Y = torch.cat(YPRED), torch.cat(Y)
+                for i, m in enumerate(metrics):
+                    if isinstance(m, str) and m in end_metrics:
+                        metric_values[i] = n_seen * end_metrics[m]()(YPRED, Y).item()
+            sums = self._allreduce_sums([total_loss, n_seen, num_correct] + list(metric_values))
+            total_loss, n_seen, num_correct = sums[0], sums[1], sums[2]
+            metric_values = np.array(sums[3:]) / n_seen
+            results = [total_loss / n_seen]
+            if self.target_type in ['cat', 'single_label']:
+                results.append(num_correct / n_seen)
+            elif self.target_type == 'multi_label':
+                results.append(num_correct / (n_seen * len(self.data.categories)))
+            if metrics:
+                results.append(metric_values)
+            return results
+
+    # ---- (5) training --------------------------------------------------------------------------------
+    def train1minibatch(self, x_batch, y_batch, lr_batch, mom_batch=None, betas_batch=None):
+        """One optimizer update on one minibatch; returns the minibatch loss as a float
+        (General/Learner.py:490-516)."""
+        bs = _batch_size(y_batch)
+        if self.grad_sync is not None:
+            bs, full_bs = self._global_bs(bs) if bs < self.data.bs else (bs, bs)
+        else:
+            full_bs = self.data.bs
+        if bs < full_bs:
+            lr_batch = list_mult(lr_batch, bs / full_bs)
+        opt = self.optimizer
+        opt.set_params(lr_batch, opt.wd, opt.bn_wd, opt.clip, **get_param_dict(mom_batch, betas_batch))
+        opt.opt.zero_grad()
+        if self.grad_sync is not None:
+            self.grad_sync.begin()
+        y_pred = self.predict1minibatch(x_batch)
+        loss = self.loss_func(y_pred, y_batch)
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    @staticmethod
+    def display_training_results(col_names, values, run_times):
+        "Epoch table (General/Learner.py:518-526)."
+        if _rank() != 0 or not Learner.verbose:
+            return
+        print("epoch".ljust(8) + "".join(c.ljust(12) for c in col_names) + '\n')
+        for n, row in enumerate(values):
+            print(str(n).ljust(8) + "".join('{:.5f}'.format(v).ljust(12) for v in row) + run_times[n])
+
+    def train_gen_sched(self, lr_sched, mom_sched, betas_sched, metrics=[], print_batch=False,
+                        save_name=None, save_method='best', swa_freq=None):
+        """Train with explicit per-minibatch schedules (General/Learner.py:528-678)."""
+        if save_name is None:
+            save_method = None
+        n_batches = len(self.data.train_dl)
+        if len(lr_sched) % n_batches != 0:
+            raise ValueError("len(lr_sched) must be an integer multiple of len(learner.data.train_dl).")
+        num_epochs = len(lr_sched) // n_batches
+
+        self.loss_sched, self.lr_sched, self.mom_sched, self.betas_sched = [], [], [], []
+        self.moving_avg_loss = 0
+        min_loss = self.evaluate('val')[0]                      # pre-training validation pass (:566)
+        if save_name:
+            self.save(save_name)
+
+        classify = self.target_type in ['cat', 'single_label', 'multi_label']
+        values, run_times = [], []
+        col_names = ['train_loss', 'val_loss'] + (['accuracy'] if classify else []) + (['metrics'] if metrics != [] else [])
+        self.display_training_results(col_names, values, run_times)
+
+        if swa_freq:
+            swa_model, swa_count = copy.deepcopy(self.model), 1
+
+        debiased = 0.
+        for n in range(num_epochs):
+            t0 = time.time()
+            self.model.train()
+            self._apply_bn_frozen()
+
+            for j, (x_batch, y_batch) in enumerate(self.data.train_dl):
+                tb = time.time()
+                x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
+                i = n * n_batches + j
+                self.lr_sched.append(lr_sched[i])
+                if mom_sched:
+                    self.mom_sched.append(mom_sched[i])
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], mom_batch=mom_sched[i])
+                elif betas_sched:
+                    self.betas_sched.append(betas_sched[i])
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], betas_batch=betas_sched[i])
+                else:
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i])
+                self.loss_sched.append(loss)
+                self.moving_avg_loss = self.moving_avg_loss * 0.98 + loss * 0.02
+                debiased = self.moving_avg_loss / (1 - 0.98 ** (i + 1))
+
+                if (print_batch is True) or (type(print_batch) == int and not isinstance(print_batch, bool)
+                                             and (j % print_batch) == 0):
+                    self._print_batch(j, debiased, loss, metrics, x_batch, y_batch, time.time() - tb)
+
+            train_loss = debiased if self.use_moving_avg else self.evaluate('train')
+
+            res = self.evaluate('val', metrics)
+            val_loss = res[0]
+            row = [train_loss, val_loss]
+            if classify:
+                row.append(res[1])
+            if metrics != []:
+                row += [mv for mv in res[-1]]
+            values.append(row)
+
+            mins, secs = divmod(time.time() - t0, 60)
+            run_times.append("  epoch run time: %d min, %.2f sec" % (mins, secs))
+            self.display_training_results(col_names, values, run_times)
+
+            if val_loss < min_loss:
+                min_loss = val_loss
+                if save_method == 'best':
+                    self.save(save_name)
+            if save_method == 'all':
+                self.save(save_name + '_' + str(n))
+
+            if swa_freq and (n + 1) % swa_freq == 0:
+                swa_model = combine_models([swa_model, self.model], [swa_count / (swa_count + 1), 1 / (swa_count + 1)])
+                swa_count += 1
+
+            if val_loss > 20 * min_loss:
+                if _rank() == 0:
+                    print('val_loss increased too much, stopping training early')
+                break
+
+        if swa_freq:
+            self.model = swa_model
+
+    def _print_batch(self, j, debiased, loss, metrics, x_batch, y_batch, dt):
+        if _rank() != 0:
+            return
+        if j == 0:
+            names = ['avg_loss', 'batch_loss'] + (['batch_metrics'] if len(metrics) > 0 else [])
+            print("batch".ljust(8) + "".join(c.ljust(12) for c in names))
+        vals = [debiased, loss]
+        if len(metrics) > 0:
+            with torch.no_grad():
+                y_pred = self.predict1minibatch(x_batch)
+                vals += [m(y_pred, y_batch).item() for m in metrics]
+        print(str(j).ljust(8) + "".join('{:.5f}'.format(v).ljust(12) for v in vals) + ("batch run time: %.2f" % dt))
+
+    def init_optimizer(self, wd=None, bn_wd=None, clip=None):
+        "Fix wd / bn_wd / clip for one training period; unspecified values keep the last ones (:680-688)."
+        WD = wd if wd else self.optimizer.wd
+        BN_WD = bn_wd if (bn_wd is not None) else self.optimizer.bn_wd
+        CLIP = clip if clip else self.optimizer.clip
+        self.optimizer.set_params(lr=0, wd=WD, bn_wd=BN_WD, clip=CLIP)
+
+    @staticmethod
+    def get_sched(sched_type, N, start_val, end_val):
+        """N schedule points of type 'linear' | 'cos' | 'exp' | 'poly' from start_val to end_val; values may be
+        per-layer-group vectors (General/Learner.py:691-728)."""
+        if type(start_val) == list:
+            start_val = np.array(start_val)
+        # NB: the reference assigns the converted end_val to a misspelt name (Learner.py:716), so a list
+        # end_val stays a list; numpy broadcasting makes every formula below work on it unchanged.
+        if sched_type == 'linear':
+            return list(linear_space(start_val, end_val, N))
+        if sched_type == 'cos':
+            s = 0.5 * (np.cos(np.linspace(0, np.pi, N)) + 1)
+            return list(end_val + outer_mult(start_val - end_val, s))
+        if sched_type == 'exp':
+            return list(np.exp(linear_space(np.log(start_val), np.log(end_val), N)))
+        if sched_type == 'poly':
+            p = np.log(end_val / start_val) / np.log(N)
+            return [start_val * i ** p for i in range(1, N + 1)]
+
+    def _check_lr_list(self, lr, name):
+        if type(lr) == list and len(lr) != len(self.model.layer_groups):
+            raise ValueError("If <%s> is a list, must have len(%s) = len(learner.model.layer_groups)." % (name, name))
+
+    def fit(self, lr, num_epochs, wd=None, bn_wd=None, clip=None, momentum=None, betas=None,
+            metrics=[], print_batch=False, save_name=None, save_method='best', swa_freq=None):
+        "Constant lr / momentum / betas for num_epochs (General/Learner.py:730-744)."
+        self._check_lr_list(lr, 'lr')
+        self.init_optimizer(wd, bn_wd, clip)
+        N = num_epochs * len(self.data.train_dl)
+        self.train_gen_sched([lr] * N, [momentum] * N if momentum else None, [betas] * N if betas else None,
+                             metrics, print_batch, save_name, save_method, swa_freq)
+
+    def fit_cycles(self, lr_start, lr_end, num_cycles, cycle_type='cos', base_length=1, cycle_mult=1,
+                   wd=None, bn_wd=None, clip=None, momentum=None, betas=None, metrics=[],
+                   print_batch=False, save_name=None, save_method='best', swa_freq=None):
+        "Annealed lr with restarts (General/Learner.py:746-774)."
+        self._check_lr_list(lr_start, 'lr_start')
+        self._check_lr_list(lr_end, 'lr_end')
+        self.init_optimizer(wd, bn_wd, clip)
+        lr_sched = []
+        mom_sched = [] if momentum else None
+        betas_sched = [] if betas else None
+        cycle_length = base_length
+        for c in range(num_cycles):
+            if c > 0:
+                cycle_length = cycle_length * cycle_mult
+            N = len(self.data.train_dl) * cycle_length
+            lr_sched += self.get_sched(cycle_type, N, lr_start, lr_end)
+            if momentum:
+                mom_sched += [momentum] * N
+            if betas:
+                betas_sched += [betas] * N
+        self.train_gen_sched(lr_sched, mom_sched, betas_sched, metrics, print_batch, save_name, save_method, swa_freq)
+
+    def fit_one_cycle(self, lr_max, num_epochs, div_fac=25, start_pct=0.3, wd=None, bn_wd=None,
+                      clip=None, mom_min=0.85, mom_max=0.95, beta_min=0.85, beta_max=0.95,
+                      metrics=[], print_batch=False, save_name=None, save_method='best'):
+        "One-cycle policy (General/Learner.py:776-802)."
+        self._check_lr_list(lr_max, 'lr_max')
+        if type(lr_max) == list:
+            lr_max = np.array(lr_max)
+        self.init_optimizer(wd, bn_wd, clip)
+        N = num_epochs * len(self.data.train_dl)
+        N1, N2 = int(N * start_pct), N - int(N * start_pct)
+        lr_min = lr_max / div_fac
+        lr_sched = self.get_sched('linear', N1, lr_min, lr_max) + self.get_sched('cos', N2, lr_max, lr_min / 1e4)
+        mom_sched, betas_sched = None, None
+        pg0 = self.optimizer.opt.param_groups[0]
+        if 'momentum' in pg0:
+            mom_sched = self.get_sched('linear', N1, mom_max, mom_min) + self.get_sched('cos', N2, mom_min, mom_max)
+        if 'betas' in pg0:
+            b = self.get_sched('linear', N1, beta_max, beta_min) + self.get_sched('cos', N2, beta_min, beta_max)
+            betas_sched = [(float(v), 0.99) for v in b]
+        self.train_gen_sched(lr_sched, mom_sched, betas_sched, metrics, print_batch, save_name, save_method)
+
+    def find_lr(self, lr_min=1e-5, lr_max=1.0, wd=None, bn_wd=None, clip=None, momentum=None,
+                betas=None, length='1epoch', break_fac=3, sched_type='exp', smoothing_radius='default',
+                plot_start_batch=0, plot=True):
+        """LR range test; model/optimizer state is restored afterwards (General/Learner.py:804-887).
+        `plot=False` (new) skips the matplotlib figure."""
+        self._check_lr_list(lr_max, 'lr_max')
+        self._check_lr_list(lr_min, 'lr_min')
+        self.save('temp', save_optimizer=True)
+        d = _dist()
+        if d:
+            d.barrier()
+        self.moving_avg_loss = 0
+        self.loss_sched, self.lr_sched, self.mom_sched, self.betas_sched = [], [], [], []
+        self.init_optimizer(wd, bn_wd, clip)
+        self.model.train()
+        self._apply_bn_frozen()
+
+        n_batches = len(self.data.train_dl)
+        N = n_batches if length == '1epoch' else length
+        num_epochs = int(np.ceil(N / n_batches))
+        lr_sched = self.get_sched(sched_type, N, lr_min, lr_max)
+        for n in range(num_epochs):
+            for j, (x_batch, y_batch) in enumerate(self.data.train_dl):
+                i = n * n_batches + j
+                x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
+                if momentum:
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], mom_batch=momentum)
+                elif betas:
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], betas_batch=betas)
+                else:
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i])
+                self.loss_sched.append(loss)
+                self.lr_sched.append(lr_sched[i])
+                self.moving_avg_loss = self.moving_avg_loss * 0.98 + loss * 0.02
+                debiased = self.moving_avg_loss / (1 - 0.98 ** (i + 1))
+                if i == 0:
+                    initial_loss = debiased
+                # as upstream, a break only leaves the current epoch's loop (Learner.py:866-867)
+                if (break_fac and debiased > break_fac * initial_loss) or i == N - 1:
+                    break
+
+        if plot and _rank() == 0:
+            import matplotlib.pyplot as plt
+            fig = plt.figure(figsize=(12, 6))
+            r = int(max(5, N / 50)) if smoothing_radius == 'default' else smoothing_radius
+            smooth = self.smooth_timeseries(self.loss_sched, r)
+            sp = fig.add_subplot(1, 2, 1)
+            plt.plot(range(plot_start_batch, len(self.lr_sched)), self.lr_sched[plot_start_batch:])
+            sp.set(xlabel='minibatch', ylabel='learning rate')
+            sp = fig.add_subplot(1, 2, 2)
+            plt.plot(self.lr_sched[plot_start_batch:], smooth[plot_start_batch:])
+            if sched_type == 'linear':
+                sp.set(xlabel='learning rate', ylabel='train loss')
+            elif sched_type == 'exp':
+                sp.set_xscale('log'); sp.set(xlabel='learning rate (log scale)', ylabel='train loss')
+
+        self.load('temp', saved_optimizer=True)

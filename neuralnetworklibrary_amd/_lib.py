@@ -1,0 +1,89 @@
+"""ctypes binding of libnnl_hip.so (the C ABI declared in include/nnl.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol cannot be bound this
+module raises at import time, and every op in ops.py refuses non-CUDA tensors.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: libnnl_hip.so binds to the libamdhip64.so.7 torch loaded)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnnl_hip.so')
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C neuralnetworklibrary_amd/csrc`). There is no CPU fallback for the HIP hot path.")
+
+lib = C.CDLL(LIB_PATH)
+
+c_p = C.c_void_p
+i32, i64, f32, f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
+sz = C.c_size_t
+
+
+class ConvGeom(C.Structure):
+    """nnl_conv_geom_t (include/nnl.h)."""
+    _fields_ = [('N', i32), ('H', i32), ('W', i32), ('C', i32), ('K', i32), ('R', i32), ('S', i32),
+                ('stride', i32), ('pad', i32), ('P', i32), ('Q', i32)]
+
+
+# name -> (restype, argtypes).  Every symbol declared in include/nnl.h must be listed here
+# (tests/test_abi.py cross-checks the header against this table and against the .so exports).
+SIGNATURES = {
+    'nnl_version': (C.c_int, []),
+    'nnl_last_error': (C.c_char_p, []),
+    'nnl_prof_enable': (C.c_int, [C.c_int]),
+    'nnl_prof_collect': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
+    'nnl_embdotbias_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int, f32, f32,
+                                     c_p, c_p]),
+    'nnl_embdotbias_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int,
+                                     f32, f32, c_p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError as e:  # fail loudly: a stale .so must not silently lose an op
+        raise ImportError(f"libnnl_hip.so does not export {_name}; rebuild it") from e
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+PROF_KINDS = ['conv_fwd', 'conv_dgrad', 'conv_wgrad', 'embdot', 'tabular', 'retina_loss', 'lstm',
+              'softmax_ce', 'elementwise', 'gemm', 'optim']
+
+
+class NnlError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        raise NnlError(f"nnl error {status}: {lib.nnl_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise NnlError("nnl HIP op called with a non-CUDA tensor: the MI355X path has no CPU fallback")
+
+
+def prof_enable(flag=True):
+    check(lib.nnl_prof_enable(1 if flag else 0))
+
+
+def prof_collect():
+    n = len(PROF_KINDS)
+    a, b, c = (i64 * n)(), (f64 * n)(), (f64 * n)()
+    check(lib.nnl_prof_collect(a, b, c))
+    return {k: {'launches': int(a[i]), 'ms': float(b[i]), 'work': float(c[i])} for i, k in enumerate(PROF_KINDS)}

@@ -1,0 +1,55 @@
+// Shared helpers for the nnl HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/nnl.h"
+
+#define NNL_WAVE 64
+
+// thread-local last-error text, returned by nnl_last_error()
+char* nnl_err_buf();
+int nnl_set_error(int code, const char* fmt, ...);
+
+#define NNL_CHECK_ARG(cond, ...)                                           \
+  do {                                                                     \
+    if (!(cond)) return nnl_set_error(NNL_ERR_INVALID_ARG, __VA_ARGS__);   \
+  } while (0)
+
+#define NNL_CHECK_HIP(expr)                                                         \
+  do {                                                                              \
+    hipError_t _e = (expr);                                                         \
+    if (_e != hipSuccess)                                                           \
+      return nnl_set_error(NNL_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+#define NNL_CHECK_LAUNCH()                                                          \
+  do {                                                                              \
+    hipError_t _e = hipGetLastError();                                              \
+    if (_e != hipSuccess)                                                           \
+      return nnl_set_error(NNL_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(_e)); \
+  } while (0)
+
+static inline int64_t nnl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// optional per-launch profiling with HIP events on the launch stream (bench.py roofline leg)
+void nnl_prof_begin(int kind, hipStream_t s);
+void nnl_prof_end(int kind, hipStream_t s, double work);
+
+struct NnlProfScope {
+  int kind; hipStream_t s; double work;
+  NnlProfScope(int k, hipStream_t st, double w) : kind(k), s(st), work(w) { nnl_prof_begin(kind, s); }
+  ~NnlProfScope() { nnl_prof_end(kind, s, work); }
+};
+
+__device__ __forceinline__ float nnl_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float nnl_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

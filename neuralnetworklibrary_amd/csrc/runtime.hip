@@ -1,0 +1,78 @@
+// Error reporting + optional per-launch HIP-event profiling for libnnl_hip.so.
+#include "nnl_common.h"
+#include <stdarg.h>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+char* nnl_err_buf() { return g_err; }
+
+int nnl_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" int nnl_version(void) { return 100; }
+extern "C" const char* nnl_last_error(void) { return g_err; }
+
+// ---- profiling: a bounded pool of event pairs, recorded on the stream each kernel is launched on ----
+namespace {
+struct ProfRec { int kind; hipEvent_t a, b; double work; };
+std::mutex g_mu;
+bool g_enabled = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_free;
+thread_local hipEvent_t g_open_a = nullptr;
+const size_t kMaxRecs = 200000;
+
+hipEvent_t get_event() {
+  if (!g_free.empty()) { hipEvent_t e = g_free.back(); g_free.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+void nnl_prof_begin(int kind, hipStream_t s) {
+  if (!g_enabled) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (g_recs.size() >= kMaxRecs) { g_open_a = nullptr; return; }
+  g_open_a = get_event();
+  if (g_open_a) (void)hipEventRecord(g_open_a, s);
+}
+
+void nnl_prof_end(int kind, hipStream_t s, double work) {
+  if (!g_enabled || !g_open_a) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  hipEvent_t b = get_event();
+  if (!b) { g_free.push_back(g_open_a); g_open_a = nullptr; return; }
+  (void)hipEventRecord(b, s);
+  g_recs.push_back({kind, g_open_a, b, work});
+  g_open_a = nullptr;
+}
+
+extern "C" int nnl_prof_enable(int enable) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_enabled = enable != 0;
+  return NNL_OK;
+}
+
+extern "C" int nnl_prof_collect(int64_t* launches, double* total_ms, double* total_work) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int k = 0; k < NNL_PROF_KINDS; ++k) { launches[k] = 0; total_ms[k] = 0; total_work[k] = 0; }
+  for (auto& r : g_recs) {
+    hipError_t e = hipEventSynchronize(r.b);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e == hipSuccess && r.kind >= 0 && r.kind < NNL_PROF_KINDS) {
+      launches[r.kind] += 1; total_ms[r.kind] += ms; total_work[r.kind] += r.work;
+    }
+    g_free.push_back(r.a); g_free.push_back(r.b);
+  }
+  g_recs.clear();
+  return NNL_OK;
+}

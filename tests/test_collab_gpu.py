@@ -1,0 +1,100 @@
+"""GPU parity of K4 (fused EmbeddingDotBias, through the C ABI) against the oracle and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, assert_close, load_golden
+from oracle import reference_math as RM
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+NAMES = ['user_emb', 'item_emb', 'user_bias', 'item_bias']
+
+
+def _net_from_golden(g, prefix='init.'):
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterNet
+    net = CollabFilterNet(int(g['n_user']), int(g['n_item']), int(g['D']), [float(g['lo']), float(g['hi'])])
+    net.load_state_dict({n + '.weight': T(g[prefix + n + '.weight']) for n in NAMES})
+    return net.to(DEV)
+
+
+def test_golden_forward_backward():
+    g = load_golden('g1_collab')
+    net = _net_from_golden(g)
+    x, y = T(g['x0'], DEV), T(g['y0'], DEV)
+    pred = net(x)
+    assert_close(pred, g['pred0'], rtol=1e-5, atol=1e-6, msg='pred')
+    loss = torch.nn.MSELoss()(pred, y)
+    assert_close(loss, g['loss0'], rtol=1e-5, msg='loss')
+    loss.backward()
+    for n in NAMES:
+        assert_close(getattr(net, n).weight.grad, g['grad0.%s.weight' % n], rtol=1e-4, atol=1e-7, msg=n)
+    net.output_range = None
+    assert_close(net(x), g['pred0_norange'], rtol=1e-5, atol=1e-6, msg='norange')
+
+
+def test_golden_three_learner_steps():
+    """Product Learner.train1minibatch x3 (Adam, wd 1e-4) vs the reference's own 3 steps."""
+    from neuralnetworklibrary_amd.General.Learner import Learner
+
+    class Data:
+        pass
+    g = load_golden('g1_collab')
+    net = _net_from_golden(g)
+    batches = [(T(g['x%d' % i], DEV), T(g['y%d' % i], DEV)) for i in range(3)]
+    d = Data(); d.train_dl = batches; d.val_dl = batches; d.bs = 64; d.target_type = 'cont'
+    learner = Learner('/tmp/nnl_test_g1', d, net, optimizer='Adam')
+    learner.init_optimizer(wd=1e-4)
+    losses = [learner.train1minibatch(x, y, 1e-2) for x, y in batches]
+    assert_close(np.array(losses), g['step_losses'], rtol=1e-5, msg='losses')
+    for n in NAMES:
+        assert_close(getattr(net, n).weight, g['after3.%s.weight' % n], rtol=1e-4, atol=1e-6, msg=n)
+
+
+@pytest.mark.parametrize('n,n_user,n_item,D,rng', [(64, 943, 1682, 30, True), (1, 5, 7, 1, True), (8192, 1000, 2000, 30, True),
+                                                   (333, 17, 19, 50, False), (4097, 64, 64, 128, True)])
+def test_vs_oracle_seeded(n, n_user, n_item, D, rng):
+    from neuralnetworklibrary_amd import ops
+    gen = torch.Generator().manual_seed(n + D)
+    x = torch.stack([torch.randint(0, n_user, (n,), generator=gen), torch.randint(0, n_item, (n,), generator=gen)], 1)
+    ps = [torch.randn(n_user, D, generator=gen) * 0.3, torch.randn(n_item, D, generator=gen) * 0.3,
+          torch.randn(n_user, 1, generator=gen), torch.randn(n_item, 1, generator=gen)]
+    dy = torch.randn(n, generator=gen)
+    orng = [0.8, 5.2] if rng else None
+    cpu = [p.clone().requires_grad_(True) for p in ps]
+    ref = RM.embdotbias(x, *cpu, orng)
+    ref.backward(dy)
+    gpu = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    out = ops.embdotbias(x.to(DEV), *gpu, orng)
+    out.backward(dy.to(DEV))
+    assert_close(out, ref, rtol=1e-5, atol=1e-5, msg='y')
+    # gathers are exact: a sample whose rows are one-hot must reproduce the table entry bit for bit
+    for a, b in zip(gpu, cpu):
+        assert_close(a.grad, b.grad, rtol=1e-3, atol=1e-5, msg='grad')
+    ops.raise_if_index_error()
+
+
+def test_gather_bit_exact():
+    """With M = all-ones rows of width 1 the output is exactly U[u,0] + bu[u] + bi[i]: the gather itself must be
+    bit-exact (north_star: 'bit-exact for embedding index gathers')."""
+    from neuralnetworklibrary_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    n_user, n_item, n = 977, 1201, 5000
+    U = torch.randn(n_user, 1, generator=gen)
+    M = torch.ones(n_item, 1)
+    z = torch.zeros(n_user, 1), torch.zeros(n_item, 1)
+    x = torch.stack([torch.randint(0, n_user, (n,), generator=gen), torch.randint(0, n_item, (n,), generator=gen)], 1)
+    out = ops.embdotbias(x.to(DEV), U.to(DEV), M.to(DEV), z[0].to(DEV), z[1].to(DEV), None).cpu()
+    assert torch.equal(out, U[x[:, 0], 0])
+
+
+def test_empty_and_out_of_range():
+    from neuralnetworklibrary_amd import ops
+    U, M = torch.randn(5, 4, device=DEV), torch.randn(6, 4, device=DEV)
+    bu, bi = torch.randn(5, 1, device=DEV), torch.randn(6, 1, device=DEV)
+    out = ops.embdotbias(torch.zeros(0, 2, dtype=torch.long, device=DEV), U, M, bu, bi, [0., 1.])
+    assert out.shape == (0,)
+    bad = torch.tensor([[0, 1], [5, 0]], device=DEV)      # user index 5 is out of range
+    ops.embdotbias(bad, U, M, bu, bi, [0., 1.])
+    with pytest.raises(IndexError):
+        ops.raise_if_index_error()
