@@ -66,6 +66,35 @@ int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float* M, const f
                        float* dU, float* dM, float* dbu, float* dbi, int64_t n, int64_t n_user,
                        int64_t n_item, int64_t D, int has_range, float lo, float hi, void* stream);
 
+/* ---- K1: conv2d as implicit GEMM on the exact-fp32 MFMA --------------------------------------------
+ * Replaces the cuDNN convolutions called by nn.Conv2d inside BasicBlock.forward / Bottleneck.forward
+ * (Applications/VisionModels/retinanet.py:43-59, 77-97), the stem (:304), the 1x1 downsample (:344-348),
+ * PyramidFeatures (:126-148) and the RetinaNet heads (:187-217, :260-295), and their autograd backward.
+ * x [N,H,W,C] NHWC, w [K,R,S,C] KRSC, y [N,P,Q,K] NHWC; P = (H+2*pad-R)/stride+1 (validated). C%4==0
+ * (the host pads the 3-channel stem input to 4), K%4==0 for dgrad/wgrad.  fp32 in, fp32 accumulate:
+ * results equal a k-ordered fmaf chain (MI355X_MICROARCH.md, Matrix cores). */
+typedef struct {
+  int32_t N, H, W, C;   /* input  NHWC */
+  int32_t K, R, S;      /* filter KRSC */
+  int32_t stride, pad;  /* same in both spatial dims (all reference convs are symmetric) */
+  int32_t P, Q;         /* output spatial size */
+} nnl_conv_geom_t;
+
+/* y = conv(x, w) (+ bias[K]) (then ReLU if relu!=0).  bias may be NULL. */
+int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
+                   int relu, void* stream);
+/* wt[C,R,S,K] = transpose of w[K,R,S,C] over (K,C): the B operand of dgrad. */
+int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
+/* dx[N,H,W,C] = sum_{r,s,k} dy[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * wt[c,r,s,k] (integral taps only). */
+int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* stream);
+/* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
+ * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */
+size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g);
+int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, const nnl_conv_geom_t* g, void* workspace,
+                     size_t workspace_bytes, void* stream);
+/* out[c] = sum_r a[r][c]  (bias gradients of conv / linear layers). */
+int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

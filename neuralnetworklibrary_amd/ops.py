@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, require_cuda, stream
 
-__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error']
+__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc']
 
 _ERR_FLAGS = {}
 
@@ -76,3 +76,88 @@ def embdotbias(x, U, M, bu, bi, output_range=None):
     """y = lo + (hi-lo)*sigmoid(<U[x[:,0]], M[x[:,1]]> + bu[x[:,0]] + bi[x[:,1]]); x int64 [n,2]."""
     lo, hi = (None, None) if output_range is None else (float(output_range[0]), float(output_range[1]))
     return _EmbDotBias.apply(x, U, M, bu, bi, lo, hi)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K1 conv2d.  Logical tensors stay NCHW / [K,C,R,S] (drop-in API, state_dict layout); the kernels see their
+# channels_last physical images: activations NHWC, filters KRSC.
+# ---------------------------------------------------------------------------------------------------------
+def to_nhwc(x):
+    """[N,C,H,W] logical -> contiguous [N,H,W,C] tensor (no copy when x is already channels_last)."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def from_nhwc(x):
+    """contiguous [N,H,W,C] -> logical [N,C,H,W] view (channels_last strides)."""
+    return x.permute(0, 3, 1, 2)
+
+
+def _geom(N, H, W, C, K, R, S, stride, pad):
+    P = (H + 2 * pad - R) // stride + 1
+    Q = (W + 2 * pad - S) // stride + 1
+    return _lib.ConvGeom(N, H, W, C, K, R, S, stride, pad, P, Q)
+
+
+def _pad_c4(t_nhwc):
+    """pad the innermost (channel) dim of an NHWC / KRSC tensor to a multiple of 4 with zeros."""
+    C = t_nhwc.shape[-1]
+    if C % 4 == 0:
+        return t_nhwc
+    return torch.nn.functional.pad(t_nhwc, (0, 4 - C % 4))
+
+
+class _Conv2d(torch.autograd.Function):
+    """nn.Conv2d forward/backward (reference Applications/VisionModels/retinanet.py:26-28,66-71,106-124,169-185,
+    241-257,304,345) on the fp32-MFMA implicit-GEMM kernels; optional fused bias + ReLU epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, relu):
+        require_cuda(x, weight, bias)
+        xn = _pad_c4(to_nhwc(_f32c(x) if x.dim() != 4 else x.float()))
+        wn = _pad_c4(to_nhwc(weight.float()))
+        N, H, W, C = xn.shape
+        K, R, S, _ = wn.shape
+        g = _geom(N, H, W, C, K, R, S, stride, pad)
+        y = torch.empty((N, g.P, g.Q, K), dtype=torch.float32, device=x.device)
+        b = None if bias is None else _f32c(bias)
+        check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), stream()))
+        ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
+        ctx.c_in = x.shape[1]
+        ctx.save_for_backward(xn, wn, y if relu else None)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, wn, y = ctx.saved_tensors
+        g = ctx.g
+        dyn = to_nhwc(dy.float())
+        if ctx.relu:
+            dyn = dyn * (y > 0)
+        K = g.K
+        if K % 4 != 0:                      # e.g. RetinaNet 36/180-channel output convs: pad dy's channels
+            dyn = _pad_c4(dyn)
+            wn = torch.nn.functional.pad(wn, (0, 0, 0, 0, 0, 0, 0, dyn.shape[-1] - K))
+            g = _geom(g.N, g.H, g.W, g.C, dyn.shape[-1], g.R, g.S, g.stride, g.pad)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
+            check(lib.nnl_conv2d_weight_transpose(ptr(wn), ptr(wt), g.K, g.R, g.S, g.C, stream()))
+            dxn = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyn.device)
+            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, stream()))
+            dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
+        if ctx.needs_input_grad[1]:
+            dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
+            ws_bytes = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
+            ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dyn.device)
+            check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
+            dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db_full = torch.empty(g.K, dtype=torch.float32, device=dyn.device)
+            check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, stream()))
+            db = db_full[:K]
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
+    """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S]."""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu))

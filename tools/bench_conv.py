@@ -1,0 +1,79 @@
+"""Per-layer microbenchmark of the implicit-GEMM conv kernels at ResNet-34 bs=64 224^2 geometries.
+Usage (GPU box): python tools/bench_conv.py [--bs 64]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralnetworklibrary_amd import _lib, ops  # noqa: E402
+from neuralnetworklibrary_amd._lib import check, lib, ptr, stream  # noqa: E402
+
+LAYERS = [  # (name, C, H, K, R, stride, pad, count in ResNet-34)
+    ('stem7x7', 4, 224, 64, 7, 2, 3, 1),
+    ('l1_3x3', 64, 56, 64, 3, 1, 1, 6),
+    ('l2_3x3s2', 64, 56, 128, 3, 2, 1, 1),
+    ('l2_1x1s2', 64, 56, 128, 1, 2, 0, 1),
+    ('l2_3x3', 128, 28, 128, 3, 1, 1, 7),
+    ('l3_3x3s2', 128, 28, 256, 3, 2, 1, 1),
+    ('l3_1x1s2', 128, 28, 256, 1, 2, 0, 1),
+    ('l3_3x3', 256, 14, 256, 3, 1, 1, 11),
+    ('l4_3x3s2', 256, 14, 512, 3, 2, 1, 1),
+    ('l4_1x1s2', 256, 14, 512, 1, 2, 0, 1),
+    ('l4_3x3', 512, 7, 512, 3, 1, 1, 5),
+]
+
+
+def timeit(fn, iters=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--bs', type=int, default=64)
+    args = ap.parse_args()
+    dev = 'cuda'
+    tot = {'fwd': 0., 'dgrad': 0., 'wgrad': 0.}
+    totf = 0.
+    print('%-10s %9s | %8s %7s | %8s %7s | %8s %7s' % ('layer', 'GFLOP', 'fwd ms', 'TF/s', 'dgrad ms', 'TF/s', 'wgrad ms', 'TF/s'))
+    for name, C, H, K, R, stride, pad, count in LAYERS:
+        N = args.bs
+        g = ops._geom(N, H, H, C, K, R, R, stride, pad)
+        x = torch.randn(N, H, H, C, device=dev)
+        w = torch.randn(K, R, R, C, device=dev) * 0.05
+        y = torch.empty(N, g.P, g.Q, K, device=dev)
+        dy = torch.randn(N, g.P, g.Q, K, device=dev)
+        wt = torch.empty(C, R, R, K, device=dev)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
+        ws = torch.empty(max(wsb // 4, 1), device=dev)
+        flop = 2.0 * N * g.P * g.Q * K * R * R * C
+        t_f = timeit(lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, stream())))
+        check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
+        t_d = timeit(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, stream())))
+        t_w = timeit(lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), wsb, stream())))
+        print('%-10s %9.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f' % (
+            name, flop / 1e9, t_f, flop / t_f / 1e9, t_d, flop / t_d / 1e9, t_w, flop / t_w / 1e9))
+        tot['fwd'] += t_f * count
+        tot['wgrad'] += t_w * count
+        if name != 'stem7x7':
+            tot['dgrad'] += t_d * count
+        totf += flop * count
+    print('ResNet-34 conv totals @bs=%d: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms; sum %.2f ms; %.1f GFLOP fwd' % (
+        args.bs, tot['fwd'], tot['dgrad'], tot['wgrad'], sum(tot.values()), totf / 1e9))
+    print('aggregate: %.1f TFLOP/s (3 passes)' % (3 * totf / sum(tot.values()) / 1e9))
+
+
+if __name__ == '__main__':
+    main()
