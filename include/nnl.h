@@ -95,6 +95,25 @@ int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, const nnl_conv_
 /* out[c] = sum_r a[r][c]  (bias gradients of conv / linear layers). */
 int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* stream);
 
+/* ---- K2: BatchNorm fused with the residual add and ReLU that follow it ---------------------------------
+ * Replaces nn.BatchNorm2d + `out += residual` + ReLU of BasicBlock/Bottleneck.forward (retinanet.py:47-48,53-57,
+ * 81-95), the stem bn1+relu (:305-306,372-373), and nn.BatchNorm1d of Linear / StructuredDataNet
+ * (General/Layers.py:35,40; StructuredData.py:1046,1078).  x,y,residual: [rows, C] row-major (NHWC: rows=N*H*W).
+ * training!=0: batch statistics (biased variance for the normalisation; running_var gets the unbiased one) and
+ *   running = (1-momentum)*running + momentum*batch   (running_* may be NULL: track_running_stats=False);
+ * training==0: normalise with running_mean / running_var.
+ * y = (x-mean)*invstd*gamma + beta [+ residual] [ReLU].  save_mean/save_invstd [C] are kept for backward. */
+size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C);
+int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+               float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
+               int64_t C, float eps, float momentum, int training, int relu, void* workspace,
+               size_t workspace_bytes, void* stream);
+/* g = dy * [y > 0] (if relu);  dbeta = sum g;  dgamma = sum g*xhat;  dres = g (if dres != NULL);
+ * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) (training) or gamma*invstd*g (eval). dgamma/dbeta may be NULL. */
+int nnl_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+               const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C,
+               int training, int relu, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,322 @@
+"""ResNet blocks, FPN, RetinaNet heads and anchors of the drop-in API (mirror of the reference's
+Applications/VisionModels/retinanet.py:26-495; the yhenon/pytorch-retinanet lineage is credited there).
+
+Same classes, constructor arguments, sub-module names (=> state_dict keys) and outputs.  Differences:
+  * every convolution is `HipConv2d`, an nn.Conv2d whose forward/backward run the fp32-MFMA implicit-GEMM
+    kernels (ops.conv2d, K1); conv+ReLU pairs of the heads use the fused ReLU epilogue;
+  * activations flow in NHWC (channels_last) between layers;
+  * `AnchorGenerator` caches the anchors per image shape ON THE DEVICE instead of rebuilding them in numpy and
+    copying H2D on every forward (retinanet.py:485-495);
+  * nms / BBoxPredictor (inference post-processing, retinanet.py:500-812) are a "next" row.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...General.Core import default_device
+
+__all__ = ['HipConv2d', 'conv3x3', 'BasicBlock', 'Bottleneck', 'PyramidFeatures', 'RegressionModel',
+           'ClassificationModel', 'RetinaNet', 'retinanet18', 'retinanet34', 'retinanet50', 'retinanet101',
+           'retinanet152', 'get_anchor_set', 'get_anchor_shifts', 'AnchorGenerator']
+
+
+class HipConv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict) computed by the HIP implicit-GEMM kernels."""
+    fuse_relu = False
+
+    def forward(self, x):
+        if self.dilation != (1, 1) or self.groups != 1 or self.stride[0] != self.stride[1] \
+                or self.padding[0] != self.padding[1] or self.padding_mode != 'zeros':
+            raise NotImplementedError('HipConv2d: only the symmetric, dense convolutions the reference uses')
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu)
+
+
+class _ConvReLU(HipConv2d):
+    "conv followed by nn.ReLU in the reference (heads, retinanet.py:192-193 etc.): ReLU fused in the epilogue"
+    fuse_relu = True
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    "3x3 convolution with padding, no bias (retinanet.py:26-28)"
+    return HipConv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+class BasicBlock(nn.Module):
+    "conv3x3-BN-ReLU-conv3x3-BN (+downsample(x)) -ReLU   (retinanet.py:30-59)"
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = ops.bn_act(self.bn1, self.conv1(x), relu=True)
+        residual = x if self.downsample is None else self.downsample(x)
+        return ops.bn_act(self.bn2, self.conv2(out), residual=residual, relu=True)
+
+
+class Bottleneck(nn.Module):
+    "1x1-BN-ReLU-3x3(stride)-BN-ReLU-1x1(x4)-BN (+downsample(x)) -ReLU   (retinanet.py:61-97)"
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = HipConv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = HipConv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = HipConv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = ops.bn_act(self.bn1, self.conv1(x), relu=True)
+        out = ops.bn_act(self.bn2, self.conv2(out), relu=True)
+        residual = x if self.downsample is None else self.downsample(x)
+        return ops.bn_act(self.bn3, self.conv3(out), residual=residual, relu=True)
+
+
+class _Downsample(nn.Sequential):
+    "Sequential(conv1x1(stride), BN) (retinanet.py:344-348) evaluated with the fused BN epilogue"
+
+    def forward(self, x):
+        return ops.bn_act(self[1], self[0](x), relu=False)
+
+
+class PyramidFeatures(nn.Module):
+    "FPN P3..P7 from C3, C4, C5 (retinanet.py:101-148)"
+
+    def __init__(self, C3_size, C4_size, C5_size, feature_size=256):
+        super().__init__()
+        self.P5_1 = HipConv2d(C5_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P5_upsampled = nn.Upsample(scale_factor=2, mode='nearest')
+        self.P5_2 = HipConv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P4_1 = HipConv2d(C4_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P4_upsampled = nn.Upsample(scale_factor=2, mode='nearest')
+        self.P4_2 = HipConv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P3_1 = HipConv2d(C3_size, feature_size, kernel_size=1, stride=1, padding=0)
+        self.P3_2 = HipConv2d(feature_size, feature_size, kernel_size=3, stride=1, padding=1)
+        self.P6 = HipConv2d(C5_size, feature_size, kernel_size=3, stride=2, padding=1)
+        self.P7_1 = nn.ReLU()
+        self.P7_2 = HipConv2d(feature_size, feature_size, kernel_size=3, stride=2, padding=1)
+
+    def forward(self, inputs):
+        C3, C4, C5 = inputs
+        P5_x = self.P5_1(C5)
+        P5_up = self.P5_upsampled(P5_x)
+        P5_x = self.P5_2(P5_x)
+        P4_x = P5_up + self.P4_1(C4)
+        P4_up = self.P4_upsampled(P4_x)
+        P4_x = self.P4_2(P4_x)
+        P3_x = self.P3_2(self.P3_1(C3) + P4_up)
+        P6_x = self.P6(C5)
+        P7_x = self.P7_2(self.P7_1(P6_x))
+        return [P3_x, P4_x, P5_x, P6_x, P7_x]
+
+
+class _Head(nn.Module):
+    """Shared structure of RegressionModel / ClassificationModel: [bn0][drop0] -> 4 x (conv3x3 -> ReLU -> [bn]
+    -> [drop]) -> output conv (retinanet.py:163-185, 232-258)."""
+
+    def _build(self, num_features_in, feature_size, n_out, bn, drop):
+        self.drop0 = nn.Dropout(drop[0]) if drop else None
+        self.drop = nn.Dropout(drop[1]) if drop else None
+        self.bn0 = nn.BatchNorm2d(num_features_in, momentum=0.01) if bn else None
+        chans = [num_features_in, feature_size, feature_size, feature_size, feature_size]
+        for i in range(1, 5):
+            setattr(self, 'conv%d' % i, _ConvReLU(chans[i - 1], feature_size, kernel_size=3, padding=1))
+            setattr(self, 'act%d' % i, nn.ReLU())          # kept for module-tree parity; fused into the conv
+            setattr(self, 'bn%d' % i, nn.BatchNorm2d(feature_size, momentum=0.01) if bn else None)
+        self.output = HipConv2d(feature_size, n_out, kernel_size=3, padding=1)
+
+    def _trunk(self, x):
+        if self.bn0:
+            x = self.bn0(x)
+        if self.drop0:
+            x = self.drop0(x)
+        out = x
+        for i in range(1, 5):
+            out = getattr(self, 'conv%d' % i)(out)            # conv + ReLU (fused)
+            bn = getattr(self, 'bn%d' % i)
+            if bn:
+                out = bn(out)
+            if self.drop:
+                out = self.drop(out)
+        return self.output(out)
+
+
+class RegressionModel(_Head):
+    "bs x C x H x W -> bs x (H*W*A) x 4, cell-major / anchor-minor (retinanet.py:150-217)"
+
+    def __init__(self, num_features_in, num_anchors=9, feature_size=256, bn=False, drop=None):
+        super().__init__()
+        self._build(num_features_in, feature_size, num_anchors * 4, bn, drop)
+
+    def forward(self, x):
+        out = self._trunk(x)                                  # logical [bs, A*4, H, W], physical NHWC
+        return out.permute(0, 2, 3, 1).reshape(out.shape[0], -1, 4)
+
+
+class ClassificationModel(_Head):
+    "bs x C x H x W -> bs x (H*W*A) x K probabilities (sigmoid inside, retinanet.py:219-295)"
+
+    def __init__(self, num_features_in, num_anchors=9, num_classes=80, feature_size=256, bn=False, drop=None):
+        super().__init__()
+        self.num_classes, self.num_anchors = num_classes, num_anchors
+        self._build(num_features_in, feature_size, num_anchors * num_classes, bn, drop)
+        self.output_act = nn.Sigmoid()
+
+    def forward(self, x):
+        out = self.output_act(self._trunk(x))
+        return out.permute(0, 2, 3, 1).reshape(out.shape[0], -1, self.num_classes)
+
+
+class RetinaNet(nn.Module):
+    "ResNet backbone + FPN + heads (retinanet.py:299-386); init: conv N(0, sqrt(2/(k*k*out))), BN (1,0), prior .01"
+
+    def __init__(self, num_classes, block, layers):
+        self.inplanes = 64
+        super().__init__()
+        self.conv1 = HipConv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        last = 'conv2' if block == BasicBlock else 'conv3'
+        fpn_sizes = [getattr(self.layer2[layers[1] - 1], last).out_channels,
+                     getattr(self.layer3[layers[2] - 1], last).out_channels,
+                     getattr(self.layer4[layers[3] - 1], last).out_channels]
+        self.fpn = PyramidFeatures(fpn_sizes[0], fpn_sizes[1], fpn_sizes[2])
+        self.regressionModel = RegressionModel(256)
+        self.classificationModel = ClassificationModel(256, num_classes=num_classes)
+        self.AnchorGenerator = AnchorGenerator()
+        init_retina_modules(self.modules())
+        prior = 0.01
+        nn.init.constant_(self.classificationModel.output.weight, 0)
+        nn.init.constant_(self.classificationModel.output.bias, -np.log((1.0 - prior) / prior))
+        nn.init.constant_(self.regressionModel.output.weight, 0)
+        nn.init.constant_(self.regressionModel.output.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = _Downsample(
+                HipConv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def stem(self, x):
+        return self.maxpool(ops.bn_act(self.bn1, self.conv1(x), relu=True))
+
+    def forward(self, img_batch):
+        x = self.stem(img_batch)
+        x1 = self.layer1(x)
+        x2 = self.layer2(x1)
+        x3 = self.layer3(x2)
+        x4 = self.layer4(x3)
+        features = self.fpn([x2, x3, x4])
+        reg = torch.cat([self.regressionModel(f) for f in features], dim=1)
+        clas = torch.cat([self.classificationModel(f) for f in features], dim=1)
+        return [self.AnchorGenerator(img_batch), reg, clas]
+
+
+def init_retina_modules(modules):
+    "conv ~ N(0, sqrt(2/(kh*kw*out))), BN weight 1 / bias 0 (retinanet.py:327-333; Vision.py:1425-1431)"
+    for m in modules:
+        if isinstance(m, nn.Conv2d):
+            n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+            nn.init.normal_(m.weight, mean=0.0, std=np.sqrt(2 / n))
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+def retinanet18(num_classes, pretrained=False, **kwargs):
+    return RetinaNet(num_classes, BasicBlock, [2, 2, 2, 2], **kwargs)
+
+
+def retinanet34(num_classes, pretrained=False, **kwargs):
+    return RetinaNet(num_classes, BasicBlock, [3, 4, 6, 3], **kwargs)
+
+
+def retinanet50(num_classes, pretrained=False, **kwargs):
+    return RetinaNet(num_classes, Bottleneck, [3, 4, 6, 3], **kwargs)
+
+
+def retinanet101(num_classes, pretrained=False, **kwargs):
+    return RetinaNet(num_classes, Bottleneck, [3, 4, 23, 3], **kwargs)
+
+
+def retinanet152(num_classes, pretrained=False, **kwargs):
+    return RetinaNet(num_classes, Bottleneck, [3, 8, 36, 3], **kwargs)
+
+
+def retinanet(weights_path=None):
+    """ResNet-50 RetinaNet with the COCO-pretrained weights when a real checkpoint file is given
+    (retinanet.py:430-435; the repository ships only an LFS pointer, so the default is random init)."""
+    model = RetinaNet(80, Bottleneck, [3, 4, 6, 3])
+    if weights_path is not None:
+        model.load_state_dict(torch.load(weights_path, map_location='cpu'))
+    return model
+
+
+# ---- anchors (retinanet.py:439-495) -----------------------------------------------------------------------
+
+def get_anchor_set(ratios=[0.5, 1, 2], scales=[2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)]):
+    "Base anchors around (0,0): area = scale, width/height = ratio; ratio-major, scale-minor order (:439-451)"
+    S = np.tile(scales, len(ratios))
+    Rt = np.repeat(ratios, len(scales))
+    Hs, Ws = S / np.sqrt(Rt), S * np.sqrt(Rt)
+    return np.array([-Ws / 2, -Hs / 2, Ws / 2, Hs / 2]).T
+
+
+def get_anchor_shifts(shape, stride, anchors):
+    "Place the A base anchors at every cell centre (i+0.5)*stride of an (H,W) grid; cell-major order (:453-471)"
+    sx = (np.arange(0, shape[1]) + 0.5) * stride
+    sy = (np.arange(0, shape[0]) + 0.5) * stride
+    sx, sy = np.meshgrid(sx, sy)
+    shifts = np.stack([sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()], axis=1)      # [K,4]
+    return (shifts[:, None, :] + anchors[None, :, :]).reshape(-1, 4)
+
+
+class AnchorGenerator(object):
+    "Anchors for pyramid levels 3..7 (stride 2^l, base size 2^(l+2)); cached per (H, W, device) (:473-495)"
+
+    def __init__(self, ratios=[0.5, 1, 2], scales=[2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3)]):
+        self.pyramid_levels = [3, 4, 5, 6, 7]
+        self.strides = [2 ** x for x in self.pyramid_levels]
+        self.sizes = [2 ** (x + 2) for x in self.pyramid_levels]
+        self.ratios, self.scales = np.array(ratios), np.array(scales)
+        self.anchor_set = get_anchor_set(ratios, scales)
+        self._cache = {}
+
+    def numpy_anchors(self, H, W):
+        shape = np.array([H, W])
+        out = []
+        for lvl, stride, size in zip(self.pyramid_levels, self.strides, self.sizes):
+            grid = (shape + 2 ** lvl - 1) // (2 ** lvl)
+            out.append(get_anchor_shifts(grid, stride, size * self.anchor_set))
+        return np.concatenate(out)
+
+    def __call__(self, img_batch):
+        key = (int(img_batch.shape[2]), int(img_batch.shape[3]), str(img_batch.device))
+        if key not in self._cache:
+            a = torch.as_tensor(self.numpy_anchors(key[0], key[1]), dtype=torch.float32)
+            self._cache[key] = a.to(img_batch.device)
+        return self._cache[key]

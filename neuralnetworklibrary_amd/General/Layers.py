@@ -57,7 +57,7 @@ class Linear(nn.Module):
             x = self.drop(x)
         x = _ops().linear(x, self.lin.weight, self.lin.bias, relu=True)
         if self.bn:
-            x = self.bn(x)
+            x = _ops().bn_act(self.bn, x, relu=False)
         return x
 
 
@@ -74,7 +74,7 @@ class Conv2d(nn.Module):
             x = self.drop(x)
         x = _ops().conv2d(x, self.conv.weight, self.conv.bias, self.conv.stride[0], self.conv.padding[0], relu=True)
         if self.bn:
-            x = self.bn(x)
+            x = _ops().bn_act(self.bn, x, relu=False)
         return x
 
 
@@ -131,7 +131,7 @@ class FullyConnectedNet(nn.Module):
 
     def forward(self, x):
         if self.pre_bn:
-            x = self.pre_bn(x)
+            x = _ops().bn_act(self.pre_bn, x, relu=False)
         for lin in self.lins:
             x = lin(x)
         x = self.final_drop(x)

@@ -46,6 +46,9 @@ SIGNATURES = {
     'nnl_conv2d_wgrad_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_wgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, sz, c_p]),
     'nnl_colsum': (C.c_int, [c_p, c_p, i64, i64, c_p]),
+    'nnl_bn_workspace_bytes': (sz, [i64, i64]),
+    'nnl_bn_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, C.c_int, c_p, sz, c_p]),
+    'nnl_bn_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, C.c_int, C.c_int, c_p, sz, c_p]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -1,0 +1,451 @@
+// K2 — BatchNorm (train / eval) fused with the residual add and ReLU that follow it in the reference's ResNet
+// blocks (retinanet.py:47-48,53-57,81-95: bn -> `out += residual` -> relu), and BatchNorm1d of the FC stacks
+// (General/Layers.py:40, StructuredData.py:1078).  HBM-bound: a [rows, C] row-major matrix (NHWC activations:
+// rows = N*H*W) is streamed with 16-B loads; algorithmic bytes per element: fwd = 4 (stats read) + 8 (apply
+// read+write) [+4 residual]; bwd = 12 (reduce reads dy,y|x) + 12..16 (apply) — see DESIGN.md.
+//
+// Statistics use the shifted-data form: S1 = sum(x - K), S2 = sum((x - K)^2) with the pivot K = x[0][c], so
+// var = (S2 - S1^2/n)/n has no catastrophic cancellation when |mean| >> std.  Per-block partial sums are combined
+// in a fixed order by a second tiny kernel => bitwise reproducible run to run.
+#include "nnl_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct VecT;
+template <> struct VecT<4> { typedef f32x4 type; };
+template <> struct VecT<1> { typedef float type; };
+
+template <int VEC> __device__ __forceinline__ float vget(const typename VecT<VEC>::type& v, int i);
+template <> __device__ __forceinline__ float vget<4>(const f32x4& v, int i) { return v[i]; }
+template <> __device__ __forceinline__ float vget<1>(const float& v, int i) { return v; }
+template <int VEC> __device__ __forceinline__ void vset(typename VecT<VEC>::type& v, int i, float x);
+template <> __device__ __forceinline__ void vset<4>(f32x4& v, int i, float x) { v[i] = x; }
+template <> __device__ __forceinline__ void vset<1>(float& v, int i, float x) { v = x; }
+
+constexpr int kBlock = 256;
+constexpr int kMaxRowBlocks = 1024;
+constexpr int kFinLanes = 64;     // partial-sum lanes per channel in the finalize kernels (4 channels per block)
+
+struct Shape {
+  int L;        // lanes per row inside a wave (power of two <= 64)
+  int rpb;      // rows covered by one block iteration = 4 waves * 64 / L
+  int gx, gy;   // grid: row blocks x channel-group tiles
+};
+
+Shape make_shape(long rows, long CG) {
+  Shape s;
+  s.L = 1;
+  while (s.L < 64 && s.L < CG) s.L <<= 1;
+  s.rpb = kBlock / s.L;
+  s.gy = (int)nnl_cdiv(CG, s.L);
+  long gx = nnl_cdiv(rows, (long)s.rpb * 4);              // at least 4 rows per thread
+  long cap = kMaxRowBlocks / (s.gy > 0 ? s.gy : 1);
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  s.gx = (int)gx;
+  return s;
+}
+
+// ---- pass 1 of training forward: partial (S1, S2) per block ------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                           long rows, int C, int L) {
+  typedef typename VecT<VEC>::type V;
+  __shared__ float red[kBlock * 2 * VEC];
+  const int CG = C / VEC;
+  const int tx = threadIdx.x & (L - 1), ty = threadIdx.x / L;
+  const int rpb = kBlock / L;
+  const int g = blockIdx.y * L + tx;
+  const bool ok = g < CG;
+  float s1[VEC], s2[VEC], piv[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; piv[e] = 0.f; }
+  if (ok) {
+    const V pv = *reinterpret_cast<const V*>(x + (long)g * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) piv[e] = vget<VEC>(pv, e);
+    const long rstep = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + ty;
+    const float* xp = x + (long)g * VEC;
+    for (; r + 3 * rstep < rows; r += 4 * rstep) {          // 4 independent 16-B loads in flight per lane
+      V v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const V*>(xp + (r + u * rstep) * C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = vget<VEC>(v[u], e) - piv[e];
+          s1[e] += d;
+          s2[e] += d * d;
+        }
+    }
+    for (; r < rows; r += rstep) {
+      const V v = *reinterpret_cast<const V*>(xp + r * C);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float d = vget<VEC>(v, e) - piv[e];
+        s1[e] += d;
+        s2[e] += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[(threadIdx.x * VEC + e) * 2 + 0] = s1[e];
+    red[(threadIdx.x * VEC + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  if (ty == 0 && ok) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int j = 0; j < rpb; ++j) {
+        a += red[((j * L + tx) * VEC + e) * 2 + 0];
+        b += red[((j * L + tx) * VEC + e) * 2 + 1];
+      }
+      const long c = (long)g * VEC + e;
+      part[((long)blockIdx.x * C + c) * 2 + 0] = a;
+      part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+  }
+}
+
+// Sum the per-block partials of channel c: 64 lanes each add a strided subset (fixed order), then a fixed-order
+// tree over the lanes in LDS.  Block = 256 threads = 4 channels x 64 lanes.  Returns the sums to lane 0.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nparts, int C, int c, bool cok,
+                                                float (*red)[kFinLanes][2], float& s1, float& s2) {
+  const int lane = threadIdx.x & (kFinLanes - 1), ch = threadIdx.x / kFinLanes;
+  float a = 0.f, b = 0.f;
+  if (cok)
+    for (int p = lane; p < nparts; p += kFinLanes) {
+      a += part[((long)p * C + c) * 2 + 0];
+      b += part[((long)p * C + c) * 2 + 1];
+    }
+  red[ch][lane][0] = a;
+  red[ch][lane][1] = b;
+  __syncthreads();
+  for (int w = kFinLanes / 2; w > 0; w >>= 1) {
+    if (lane < w) {
+      red[ch][lane][0] += red[ch][lane + w][0];
+      red[ch][lane][1] += red[ch][lane + w][1];
+    }
+    __syncthreads();
+  }
+  s1 = red[ch][0][0];
+  s2 = red[ch][0][1];
+}
+
+// ---- finalize: mean / invstd, running statistics, per-channel scale & shift ----------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale, float* __restrict__ shift, long rows, int C, float eps,
+                                   float momentum) {
+  __shared__ float red[4][kFinLanes][2];
+  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
+  float s1, s2;
+  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
+  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
+  const float n = (float)rows;
+  const float m = x[c] + s1 / n;
+  float var = (s2 - s1 * (s1 / n)) / n;
+  var = fmaxf(var, 0.f);
+  const float is = 1.f / sqrtf(var + eps);
+  mean[c] = m;
+  invstd[c] = is;
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+  if (running_var) {
+    const float unbiased = rows > 1 ? var * (n / (n - 1.f)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+  const float gm = gamma ? gamma[c] : 1.f;
+  const float sc = is * gm;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - m * sc;
+}
+
+__global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ invstd,
+                                     int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(running_var[c] + eps);
+  const float sc = is * (gamma ? gamma[c] : 1.f);
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - running_mean[c] * sc;
+  if (invstd) invstd[c] = is;
+}
+
+// ---- apply: y = x*scale + shift (+ residual) (ReLU) ---------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ residual, float* __restrict__ y,
+                                                           long total_v, int CG, int relu) {
+  typedef typename VecT<VEC>::type V;
+  const long stride = (long)gridDim.x * blockDim.x;          // host guarantees stride % CG == 0
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = (int)((unsigned)i0 % (unsigned)CG);
+  const V sc = reinterpret_cast<const V*>(scale)[g];
+  const V sh = reinterpret_cast<const V*>(shift)[g];
+  for (long i = i0; i < total_v; i += stride) {
+    const V xv = reinterpret_cast<const V*>(x)[i];
+    V out;
+    if (residual) {
+      const V rv = reinterpret_cast<const V*>(residual)[i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, vget<VEC>(xv, e) * vget<VEC>(sc, e) + vget<VEC>(sh, e) + vget<VEC>(rv, e));
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, vget<VEC>(xv, e) * vget<VEC>(sc, e) + vget<VEC>(sh, e));
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, fmaxf(vget<VEC>(out, e), 0.f));
+    }
+    reinterpret_cast<V*>(y)[i] = out;
+  }
+}
+
+// ---- backward pass 1: partial (sum g, sum g*xhat) per block, g = dy * [y > 0] ---------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                const float* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, float* __restrict__ part,
+                                                                long rows, int C, int L, int relu) {
+  typedef typename VecT<VEC>::type V;
+  __shared__ float red[kBlock * 2 * VEC];
+  const int CG = C / VEC;
+  const int tx = threadIdx.x & (L - 1), ty = threadIdx.x / L;
+  const int rpb = kBlock / L;
+  const int g = blockIdx.y * L + tx;
+  const bool ok = g < CG;
+  float s1[VEC], s2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = 0.f; is[e] = 0.f; }
+  if (ok) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mu[e] = mean[(long)g * VEC + e]; is[e] = invstd[(long)g * VEC + e]; }
+    const long rstep = (long)gridDim.x * rpb;
+    long r = (long)blockIdx.x * rpb + ty;
+    for (; r + rstep < rows; r += 2 * rstep) {              // 2 x 3 independent 16-B loads in flight per lane
+      V dv[2], xv[2], yv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long off = (r + u * rstep) * C + (long)g * VEC;
+        dv[u] = *reinterpret_cast<const V*>(dy + off);
+        xv[u] = *reinterpret_cast<const V*>(x + off);
+        yv[u] = dv[u];
+        if (relu) yv[u] = *reinterpret_cast<const V*>(y + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float gg = vget<VEC>(dv[u], e);
+          if (relu && !(vget<VEC>(yv[u], e) > 0.f)) gg = 0.f;
+          s1[e] += gg;
+          s2[e] += gg * ((vget<VEC>(xv[u], e) - mu[e]) * is[e]);
+        }
+    }
+    for (; r < rows; r += rstep) {
+      const long off = r * C + (long)g * VEC;
+      const V dv = *reinterpret_cast<const V*>(dy + off);
+      const V xv = *reinterpret_cast<const V*>(x + off);
+      V yv = dv;
+      if (relu) yv = *reinterpret_cast<const V*>(y + off);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float gg = vget<VEC>(dv, e);
+        if (relu && !(vget<VEC>(yv, e) > 0.f)) gg = 0.f;
+        s1[e] += gg;
+        s2[e] += gg * ((vget<VEC>(xv, e) - mu[e]) * is[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[(threadIdx.x * VEC + e) * 2 + 0] = s1[e];
+    red[(threadIdx.x * VEC + e) * 2 + 1] = s2[e];
+  }
+  __syncthreads();
+  if (ty == 0 && ok) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int j = 0; j < rpb; ++j) {
+        a += red[((j * L + tx) * VEC + e) * 2 + 0];
+        b += red[((j * L + tx) * VEC + e) * 2 + 1];
+      }
+      const long c = (long)g * VEC + e;
+      part[((long)blockIdx.x * C + c) * 2 + 0] = a;
+      part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+  }
+}
+
+// finalize backward: dbeta, dgamma and the three per-channel coefficients of dx = a*g + b*x + c0
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef,
+                                       long rows, int C, int training) {
+  __shared__ float red[4][kFinLanes][2];
+  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
+  float s1, s2;
+  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
+  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
+  if (dbeta) dbeta[c] = s1;
+  if (dgamma) dgamma[c] = s2;
+  const float gm = gamma ? gamma[c] : 1.f;
+  const float is = invstd[c], mu = mean[c];
+  const float a = gm * is;
+  if (training) {
+    // dx = a * (g - s1/n - xhat*s2/n),  xhat = (x - mu)*is   =>  dx = a*g + bq*x + c0
+    const float n = (float)rows;
+    const float bq = -a * is * (s2 / n);
+    coef[c] = a;
+    coef[C + c] = bq;
+    coef[2 * C + c] = -a * (s1 / n) - bq * mu;
+  } else {
+    coef[c] = a;
+    coef[C + c] = 0.f;
+    coef[2 * C + c] = 0.f;
+  }
+}
+
+// ---- backward pass 2: dx = a*g + b*x + c0 ; dres = g -----------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               const float* __restrict__ x, const float* __restrict__ coef,
+                                                               float* __restrict__ dx, float* __restrict__ dres,
+                                                               long total_v, int CG, int C, int relu) {
+  typedef typename VecT<VEC>::type V;
+  const long stride = (long)gridDim.x * blockDim.x;          // host guarantees stride % CG == 0
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = (int)((unsigned)i0 % (unsigned)CG);
+  const V ca = reinterpret_cast<const V*>(coef)[g];
+  const V cb = reinterpret_cast<const V*>(coef + C)[g];
+  const V cc = reinterpret_cast<const V*>(coef + 2 * C)[g];
+  for (long i = i0; i < total_v; i += stride) {
+    const V dv = reinterpret_cast<const V*>(dy)[i];
+    const V xv = reinterpret_cast<const V*>(x)[i];
+    V gv = dv;
+    if (relu) {
+      const V yv = reinterpret_cast<const V*>(y)[i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        if (!(vget<VEC>(yv, e) > 0.f)) vset<VEC>(gv, e, 0.f);
+    }
+    V out;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      vset<VEC>(out, e, vget<VEC>(ca, e) * vget<VEC>(gv, e) + vget<VEC>(cb, e) * vget<VEC>(xv, e) + vget<VEC>(cc, e));
+    reinterpret_cast<V*>(dx)[i] = out;
+    if (dres) reinterpret_cast<V*>(dres)[i] = gv;
+  }
+}
+
+long gcd_l(long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; }
+
+// grid such that grid*kBlock is a multiple of CG: every thread then keeps ONE channel group for its whole
+// grid-stride loop (no per-element modulo, per-channel coefficients live in registers)
+int ew_grid(long total_v, long CG) {
+  const long unit = CG / gcd_l(CG, kBlock);                 // blocks per aligned period
+  long b = nnl_cdiv(total_v, (long)kBlock * 2);             // ~2 vectors per thread
+  if (b > 8192) b = 8192;
+  b = nnl_cdiv(b, unit) * unit;
+  if (b < unit) b = unit;
+  return (int)b;
+}
+
+}  // namespace
+
+// workspace layout (floats): [partials: kMaxRowBlocks*C*2][scale C][shift C][coef 3C]
+extern "C" size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)((long)kMaxRowBlocks * C * 2 + 5 * C) * sizeof(float);
+}
+
+extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
+                          float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
+                          int64_t C, float eps, float momentum, int training, int relu, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_fwd: bad sizes rows=%ld C=%ld", (long)rows, (long)C);
+  NNL_CHECK_ARG(x && y && save_mean && save_invstd, "bn_fwd: null pointer");
+  NNL_CHECK_ARG(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* scale = part + (long)kMaxRowBlocks * C * 2;
+  float* shift = scale + C;
+  const int VEC = (C % 4 == 0) ? 4 : 1;
+  const long CG = C / VEC;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (training ? 12.0 : 8.0) + (residual ? 4.0 * rows * C : 0.0));
+  if (training) {
+    const Shape sh = make_shape(rows, CG);
+    if (VEC == 4)
+      hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, (long)rows, (int)C, sh.L);
+    else
+      hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, (long)rows, (int)C, sh.L);
+    NNL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
+                       save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps, momentum);
+    NNL_CHECK_LAUNCH();
+  } else {
+    NNL_CHECK_HIP(hipMemcpyAsync(save_mean, running_mean, sizeof(float) * C, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(bn_eval_scale_kernel, dim3((unsigned)nnl_cdiv(C, 256)), dim3(256), 0, s, gamma, beta, running_mean,
+                       running_var, scale, shift, save_invstd, (int)C, eps);
+    NNL_CHECK_LAUNCH();
+  }
+  const long total_v = rows * CG;
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
+                       (int)CG, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
+                       (int)CG, relu);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+                          const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows,
+                          int64_t C, int training, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_bwd: bad sizes");
+  NNL_CHECK_ARG(dy && x && mean && invstd && dx && (y || !relu), "bn_bwd: null pointer");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* coef = part + (long)kMaxRowBlocks * C * 2 + 2 * C;
+  const int VEC = (C % 4 == 0) ? 4 : 1;
+  const long CG = C / VEC;
+  const Shape sh = make_shape(rows, CG);
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (relu ? 28.0 : 20.0) + (dres ? 4.0 * rows * C : 0.0));
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
+                       (int)C, sh.L, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
+                       (int)C, sh.L, relu);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, part, sh.gx, gamma, mean, invstd,
+                     dgamma, dbeta, coef, (long)rows, (int)C, training);
+  NNL_CHECK_LAUNCH();
+  const long total_v = rows * CG;
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
+                       (int)CG, (int)C, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
+                       (int)CG, (int)C, relu);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}

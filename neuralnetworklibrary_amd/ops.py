@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, require_cuda, stream
 
-__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc']
+__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc', 'linear', 'bn_act', 'concat_pool2d']
 
 _ERR_FLAGS = {}
 
@@ -161,3 +161,85 @@ class _Conv2d(torch.autograd.Function):
 def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
     """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S]."""
     return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu))
+
+
+def linear(x, weight, bias=None, relu=False):
+    """y = x @ weight.T + bias [+ ReLU] (nn.Linear; reference General/Layers.py:39,146; Text.py:572) on the same
+    fp32-MFMA implicit-GEMM kernels: a Linear is the 1x1 convolution of a 1x1 'image' per sample.  Leading dims of x
+    are flattened into rows."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, bool(relu))
+    return y.reshape(*lead, weight.shape[0])
+
+
+def _rows_view(x):
+    """logical [N,C,H,W] (or [rows,C]) -> contiguous [rows, C] matrix + a function mapping such a matrix back."""
+    if x.dim() == 4:
+        xn = to_nhwc(x.float())
+        N, H, W, C = xn.shape
+        return xn.view(-1, C), (lambda m: from_nhwc(m.view(N, H, W, C)))
+    if x.dim() == 2:
+        return _f32c(x), (lambda m: m)
+    if x.dim() == 3:                                    # BatchNorm1d on [N, C, L]
+        xn = x.float().permute(0, 2, 1).contiguous()
+        N, L, C = xn.shape
+        return xn.view(-1, C), (lambda m: m.view(N, L, C).permute(0, 2, 1))
+    raise ValueError('bn_act: unsupported input rank %d' % x.dim())
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+        require_cuda(x, residual, gamma, beta)
+        xm, back = _rows_view(x)
+        rows, C = xm.shape
+        rm = None if residual is None else _rows_view(residual)[0]
+        y = torch.empty_like(xm)
+        mean = torch.empty(C, dtype=torch.float32, device=xm.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=xm.device)
+        wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
+        check(lib.nnl_bn_fwd(ptr(xm), ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
+                             ptr(running_var), rows, C, float(eps), float(momentum), int(training), int(relu), ptr(ws),
+                             wsb, stream()))
+        ctx.save_for_backward(xm, y if relu else None, gamma, mean, invstd)
+        ctx.cfg = (training, relu, residual is not None, back)
+        return back(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, y, gamma, mean, invstd = ctx.saved_tensors
+        training, relu, has_res, back = ctx.cfg
+        dym = _rows_view(dy)[0]
+        rows, C = xm.shape
+        dx = torch.empty_like(xm)
+        dres = torch.empty_like(xm) if (has_res and ctx.needs_input_grad[1]) else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=xm.device) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=xm.device) if gamma is not None else None
+        wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
+        check(lib.nnl_bn_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
+                             ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta, None, None, None, None, None, None)
+
+
+def bn_act(bn, x, residual=None, relu=True):
+    """BatchNorm (train: batch statistics + running-stat update; eval: running stats) -> (+ residual) -> ReLU in the HIP
+    kernels of batchnorm.hip: the bn -> `out += residual` -> relu tail of BasicBlock / Bottleneck (reference
+    retinanet.py:47-48,53-57,81-95), the stem (:372-373) and the BatchNorm1d layers (General/Layers.py:40).
+    `bn` is the nn.BatchNorm{1,2}d module holding weight / bias / running stats (state_dict unchanged)."""
+    training = bn.training or (bn.running_mean is None)
+    momentum = 0.0
+    if bn.training and bn.track_running_stats:
+        if bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+    rmean = bn.running_mean if (not training or bn.track_running_stats) else None
+    rvar = bn.running_var if (not training or bn.track_running_stats) else None
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu)
+
+
+def concat_pool2d(x):
+    """cat([global max pool, global avg pool], 1) -> [N, 2C, 1, 1]  (AdaptiveConcatPool2d, General/Layers.py:78-87)."""
+    return torch.cat([x.amax(dim=(2, 3), keepdim=True), x.mean(dim=(2, 3), keepdim=True)], 1)

@@ -14,6 +14,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import _ref_import  # noqa: E402
+import synth  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 os.makedirs(OUT, exist_ok=True)
@@ -79,7 +80,115 @@ def g1_collab():
     save('g1_collab', **out)
 
 
-GROUPS = {'g1': g1_collab}
+def g5_blocks():
+    """G5: BasicBlock(8,8), strided BasicBlock(8,16,2)+downsample, stem conv7x7+BN+ReLU+maxpool: outputs, input and
+    parameter gradients, BN running stats after one training-mode forward.  Weights/inputs from synth.py."""
+    RN = R['Applications.VisionModels.retinanet']
+    nn = torch.nn
+    out = {}
+
+    def run(tag, mod, x):
+        synth.fill_module_(mod)
+        mod.train()
+        x = x.clone().requires_grad_(True)
+        y = mod(x)
+        dy = synth.synth_input(tuple(y.shape), 77 + len(out), 1.0)
+        y.backward(dy)
+        out[tag + '.y'], out[tag + '.dy'], out[tag + '.dx'] = A(y), A(dy), A(x.grad)
+        for n, p in mod.named_parameters():
+            out[tag + '.grad.' + n] = A(p.grad)
+        for n, b in mod.named_buffers():
+            out[tag + '.buf.' + n] = A(b)
+
+    run('bb', RN.BasicBlock(8, 8), synth.synth_input((2, 8, 14, 14), 1))
+    ds = nn.Sequential(nn.Conv2d(8, 16, kernel_size=1, stride=2, bias=False), nn.BatchNorm2d(16))
+    run('bbs', RN.BasicBlock(8, 16, 2, ds), synth.synth_input((2, 8, 14, 14), 2))
+    ds = nn.Sequential(nn.Conv2d(8, 16, kernel_size=1, stride=2, bias=False), nn.BatchNorm2d(16))
+    run('bn', RN.Bottleneck(8, 4, 2, ds), synth.synth_input((2, 8, 14, 14), 3))
+    stem = nn.Sequential(nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+                         nn.ReLU(inplace=True), nn.MaxPool2d(kernel_size=3, stride=2, padding=1))
+    run('stem', stem, synth.synth_input((2, 3, 32, 32), 4))
+    save('g5_blocks', **out)
+
+
+def g6_resnet34():
+    """G6: the reference's ImageClassificationNet over a ResNet-34 body (RetinaNet(.,BasicBlock,[3,4,6,3]) cut at
+    child 8, split at 6 = default_cut/default_split of a torchvision ResNet, Vision.py:1211-1212,1225-1228) + default
+    head (dropout 0) on x [4,3,96,96]: logits, CE loss, per-parameter gradient norms and gradient slices — each from
+    the reference in fp32 AND from the same reference modules cast to fp64 (training-mode BN at small batch is
+    ill-conditioned: fp32 and fp64 runs of the reference itself differ by ~1e-3 on early-layer gradients, so tests
+    bound the error of any fp32 implementation by the reference's own fp32-vs-fp64 gap).  Then one real
+    Learner.train1minibatch (SGD momentum 0.9, lr [1e-3,3e-3,1e-2], wd 1e-4) and post-step parameter checksums."""
+    RN = R['Applications.VisionModels.retinanet']
+    V = R['Applications.Vision']
+    N, S = 4, 96
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
+
+    def make(dtype):
+        arch = RN.RetinaNet(2, RN.BasicBlock, [3, 4, 6, 3])
+        net = V.ImageClassificationNet(D, arch, head=[[512], [0., 0.]], cutpoint=8, splits=[6])
+        synth.fill_module_(net)
+        return net.to(dtype).train()
+
+    x, y = synth.synth_input((N, 3, S, S), 6), torch.arange(N) % 2
+    out = {'N': N, 'S': S}
+    slices = ['body.0.weight', 'body.4.0.conv1.weight', 'body.5.0.downsample.0.weight', 'body.7.2.conv2.weight',
+              'head.2.lins.0.lin.weight', 'head.2.final_lin.bias']
+    for tag, dtype in [('f32', torch.float32), ('f64', torch.float64)]:
+        net = make(dtype)
+        logits = net(x.to(dtype))
+        loss = torch.nn.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        out['logits.' + tag], out['loss.' + tag] = A(logits).astype(np.float64), A(loss).astype(np.float64)
+        out['grad_norms.' + tag] = np.array([p.grad.norm().item() for _, p in net.named_parameters()], dtype=np.float64)
+        sd = dict(net.named_parameters())
+        for n in slices:
+            out['grad.%s.%s' % (n, tag)] = A(sd[n].grad).reshape(-1)[:2048].astype(np.float64)
+        # eval-mode BatchNorm (running statistics: no batch-statistics chaos) — a WELL-conditioned full-depth
+        # forward/backward used for the strict elementwise gradient comparison
+        net.eval()
+        for p in net.parameters():
+            p.grad = None
+        logits = net(x.to(dtype))
+        loss = torch.nn.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        out['eval.logits.' + tag], out['eval.loss.' + tag] = A(logits).astype(np.float64), A(loss).astype(np.float64)
+        out['eval.grad_norms.' + tag] = np.array([p.grad.norm().item() for _, p in net.named_parameters()], dtype=np.float64)
+        for n in slices:
+            out['eval.grad.%s.%s' % (n, tag)] = A(sd[n].grad).reshape(-1)[:2048].astype(np.float64)
+        net.train()
+        if tag == 'f32':
+            out['param_names'] = np.array([n for n, _ in net.named_parameters()])
+            out['buf.body.1.running_mean'] = A(net.body[1].running_mean)
+            out['buf.body.1.running_var'] = A(net.body[1].running_var)
+            out['n_layer_groups'] = len(net.layer_groups)
+    # one real optimizer step through the reference Learner (fresh fp32 net)
+    net = make(torch.float32)
+    d = D(); d.train_dl = [(x, y)]; d.val_dl = [(x, y)]
+    learner = Learner('/tmp/nnl_golden_g6', d, net, optimizer='SGD_Mom')
+    learner.init_optimizer(wd=1e-4)
+    out['step_loss'] = np.array([learner.train1minibatch(x, y, [1e-3, 3e-3, 1e-2])], dtype=np.float64)
+    out['after.sums'] = np.array([p.double().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+    out['after.abs_sums'] = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+    # the same step with every BatchNorm frozen (Learner.bn_freeze('all') + the m.training=False loop of
+    # train_gen_sched, Learner.py:248-264,589-591): running statistics instead of batch statistics => well conditioned
+    net = make(torch.float32)
+    learner = Learner('/tmp/nnl_golden_g6', d, net, optimizer='SGD_Mom')
+    learner.bn_freeze('all')
+    learner.init_optimizer(wd=1e-4)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.training = False
+    out['frozen.step_loss'] = np.array([learner.train1minibatch(x, y, [1e-3, 3e-3, 1e-2])], dtype=np.float64)
+    out['frozen.after.sums'] = np.array([p.double().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+    out['frozen.after.abs_sums'] = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+    save('g6_resnet34', **out)
+
+
+GROUPS = {'g1': g1_collab, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)
