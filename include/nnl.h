@@ -114,6 +114,50 @@ int nnl_bn_bwd(const float* dy, const float* y, const float* x, const float* gam
                const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                int training, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- K3: categorical-embedding front end of StructuredDataNet --------------------------------------------
+ * Replaces, per categorical column j, EmbeddingDrop.forward (General/Layers.py:74-76: nn.Embedding(max_norm=1.5)
+ * in-place renorm + gather + per-sample dropout mask) and the two torch.cat calls of StructuredDataNet.forward
+ * (Applications/StructuredData.py:1075-1082).  Descriptor arrays are DEVICE arrays with one entry per column:
+ * tables[j] (pointer to W_j [card[j], dim[j]]), card, dim, col_off (first output column of column j);
+ * col_table[c] = column owning output column c (c < cat_width = sum dim); row_off[j] = first global row id of
+ * table j, row_table[r] = table owning global row r (r < total_rows = sum card); flags: int32[total_rows], zero
+ * on entry and on exit. */
+/* In-place max_norm renormalisation of every row looked up by xcat [bs, ncat] (each distinct row exactly once):
+ * rows with L2 norm > max_norm are scaled by max_norm/(norm+1e-7)  (torch embedding_renorm_). */
+int nnl_tab_renorm(const int64_t* xcat, float* const* tables, const int32_t* card, const int32_t* dim,
+                   const int32_t* row_off, const int32_t* row_table, int32_t* flags, int64_t bs, int32_t ncat,
+                   int32_t total_rows, float max_norm, int32_t* err_flag, void* stream);
+/* out [bs, ld_out]: columns [col_off[j], +dim[j]) = tables[j][xcat[b,j]] * row_mask[j,b]  (row_mask [ncat,bs] or
+ * NULL = ones); columns [cat_width, +n_cont) = cont[b,:] * cont_mask[b,:] (cont_mask NULL = ones); rest = 0. */
+int nnl_tab_gather_fwd(const int64_t* xcat, const float* const* tables, const int32_t* card, const int32_t* dim,
+                       const int32_t* col_off, const int32_t* col_table, const float* row_mask, const float* cont,
+                       const float* cont_mask, float* out, int64_t bs, int32_t ncat, int32_t cat_width,
+                       int32_t n_cont, int32_t ld_out, void* stream);
+/* Backward: dense table gradients (nn.Embedding sparse=False) scatter-added into ONE flat zero-filled buffer
+ * dtab_flat (table j at element offset grad_off[j]), and dcont [bs, n_cont] = dout[:, cat_width:] * cont_mask. */
+int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, const int32_t* dim, const int32_t* col_off,
+                        const int32_t* col_table, const int64_t* grad_off, const float* row_mask,
+                        const float* cont_mask, const float* dout, float* dtab_flat, int64_t dtab_elems,
+                        float* dcont, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out,
+                        void* stream);
+
+/* ---- K6: fused RetinaNet detection loss (anchor matching + focal + smooth-L1) -----------------------------
+ * Replaces SSD_loss.__call__ and everything it calls per image (Applications/Vision.py:1620-1644 -> ssd1 :1568-1605,
+ * match_anchors_objects :1474-1511, jaccard :234-256, focal_loss_retina :1513-1530, smoothL1_loss_retina :1532-1566).
+ * anchors [A,4]; reg [bs,A,4]; clas [bs,A,K] (probabilities); boxes [bs,M,4], cats int64 [bs,M], both padded with -1
+ * (Vision.py:798-809), M <= 128.  Outputs: out[3] = {(1-beta)*reg + beta*clas, reg_loss, clas_loss} (batch means),
+ * state int32 [bs,A] (>=0 matched object, -1 negative, -2 ignored) and npos float [bs] are kept for backward. */
+size_t nnl_retina_loss_workspace_bytes(int64_t bs, int64_t A);
+int nnl_retina_loss_fwd(const float* anchors, const float* reg, const float* clas, const float* boxes,
+                        const int64_t* cats, int32_t* state, float* npos, float* out, int64_t bs, int64_t A,
+                        int64_t K, int64_t M, float beta, float alpha, float gamma, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* dreg [bs,A,4], dclas [bs,A,K] = d out[0] / d reg, d clas times *grad_out (device scalar). */
+int nnl_retina_loss_bwd(const float* anchors, const float* reg, const float* clas, const float* boxes,
+                        const int64_t* cats, const int32_t* state, const float* npos, const float* grad_out,
+                        float* dreg, float* dclas, int64_t bs, int64_t A, int64_t K, int64_t M, float beta,
+                        float alpha, float gamma, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,12 @@ SIGNATURES = {
     'nnl_conv2d_wgrad_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_wgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, sz, c_p]),
     'nnl_colsum': (C.c_int, [c_p, c_p, i64, i64, c_p]),
+    'nnl_tab_renorm': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, f32, c_p, c_p]),
+    'nnl_tab_gather_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, c_p]),
+    'nnl_tab_scatter_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i32, i32, i32, i32, c_p]),
+    'nnl_retina_loss_workspace_bytes': (sz, [i64, i64]),
+    'nnl_retina_loss_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, f32, f32, f32, c_p, sz, c_p]),
+    'nnl_retina_loss_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, f32, f32, f32, c_p]),
     'nnl_bn_workspace_bytes': (sz, [i64, i64]),
     'nnl_bn_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, C.c_int, c_p, sz, c_p]),
     'nnl_bn_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, C.c_int, C.c_int, c_p, sz, c_p]),

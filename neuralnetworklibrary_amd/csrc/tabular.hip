@@ -1,0 +1,167 @@
+// K3 — the categorical-embedding front end of StructuredDataNet (Applications/StructuredData.py:1072-1084):
+// per column j: nn.Embedding(max_norm) in-place renorm of the looked-up rows, gather, per-SAMPLE dropout mask
+// (EmbeddingDrop.forward, General/Layers.py:74-76), torch.cat of all columns, and the concat with the (already
+// batch-normed, dropped-out) continuous block — one gather kernel instead of ~5 launches per column.
+//
+// HBM/gather-bound and tiny: per sample 8*ncat B of indices + 4*sum(d_j) B gathered + 4*D_out B written.
+// Descriptors live in device memory: tables[j] (pointer), card[j], dim[j], col_off[j] (first output column).
+#include "nnl_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// flags[row_off[j] + idx] = 1 for every looked-up row (idempotent scatter)
+__global__ void tab_mark_kernel(const int64_t* __restrict__ xcat, const int32_t* __restrict__ card,
+                                const int32_t* __restrict__ row_off, int32_t* __restrict__ flags, long bs, int ncat,
+                                int32_t* __restrict__ err_flag) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bs * ncat) return;
+  const int j = (int)(i % ncat);
+  const int64_t idx = xcat[i];
+  if (idx < 0 || idx >= card[j]) { if (err_flag) *err_flag = 1; return; }
+  flags[row_off[j] + idx] = 1;
+}
+
+// one 16-lane group per table row: if flagged, renormalise to L2 norm <= max_norm exactly like torch's
+// embedding_renorm_ (scale = max_norm / (norm + 1e-7) when norm > max_norm), then clear the flag
+__global__ void tab_renorm_kernel(float* const* __restrict__ tables, const int32_t* __restrict__ dim,
+                                  const int32_t* __restrict__ row_off, const int32_t* __restrict__ row_table,
+                                  int32_t* __restrict__ flags, int total_rows, float max_norm) {
+  const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  if (grp >= total_rows) return;
+  if (flags[grp] == 0) return;                       // uniform inside the 16-lane group
+  const int j = row_table[grp];
+  const int d = dim[j];
+  float* row = tables[j] + (long)(grp - row_off[j]) * d;
+  float ss = 0.f;
+  for (int e = sub; e < d; e += 16) { const float v = row[e]; ss += v * v; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float norm = sqrtf(ss);
+  if (norm > max_norm) {
+    const float scale = max_norm / (norm + 1e-7f);
+    for (int e = sub; e < d; e += 16) row[e] *= scale;
+  }
+  if (sub == 0) flags[grp] = 0;
+}
+
+// out[b, col_off[j] + e] = tables[j][xcat[b,j], e] * row_mask[j, b];  out[b, cat_width + e] = cont[b,e]*cont_mask[b,e];
+// columns >= cat_width + n_cont (padding up to ld_out) are zero-filled.
+__global__ void tab_gather_kernel(const int64_t* __restrict__ xcat, const float* const* __restrict__ tables,
+                                  const int32_t* __restrict__ card, const int32_t* __restrict__ dim,
+                                  const int32_t* __restrict__ col_off, const int32_t* __restrict__ col_table,
+                                  const float* __restrict__ row_mask, const float* __restrict__ cont,
+                                  const float* __restrict__ cont_mask, float* __restrict__ out, long bs, int ncat,
+                                  int cat_width, int n_cont, int ld_out) {
+  // thread <-> one output element; consecutive threads walk one sample's row (coalesced 4-B stores)
+  const long total = bs * ld_out;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ld_out;
+    const int col = (int)(i - b * ld_out);
+    float v = 0.f;
+    if (col < cat_width) {
+      const int j = col_table[col];
+      const int64_t idx = xcat[b * ncat + j];
+      if (idx >= 0 && idx < card[j]) {
+        v = tables[j][idx * dim[j] + (col - col_off[j])];
+        if (row_mask) v *= row_mask[(long)j * bs + b];
+      }
+    } else if (col < cat_width + n_cont) {
+      const int e = col - cat_width;
+      v = cont[b * n_cont + e];
+      if (cont_mask) v *= cont_mask[b * n_cont + e];
+    }
+    out[i] = v;
+  }
+}
+
+// dtab_flat[grad_off[j] + idx*d + e] += dout[b, col_off[j]+e] * row_mask[j,b];  dcont[b,e] = dout[b,cat_width+e]*cont_mask
+__global__ void tab_scatter_kernel(const int64_t* __restrict__ xcat, const int32_t* __restrict__ card,
+                                   const int32_t* __restrict__ dim, const int32_t* __restrict__ col_off,
+                                   const int32_t* __restrict__ col_table, const int64_t* __restrict__ grad_off,
+                                   const float* __restrict__ row_mask, const float* __restrict__ cont_mask,
+                                   const float* __restrict__ dout, float* __restrict__ dtab_flat, float* __restrict__ dcont,
+                                   long bs, int ncat, int cat_width, int n_cont, int ld_out) {
+  const int width = cat_width + n_cont;
+  const long total = bs * width;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / width;
+    const int col = (int)(i - b * width);
+    const float g = dout[b * ld_out + col];
+    if (col < cat_width) {
+      const int j = col_table[col];
+      const int64_t idx = xcat[b * ncat + j];
+      if (idx >= 0 && idx < card[j]) {
+        const float m = row_mask ? row_mask[(long)j * bs + b] : 1.f;
+        if (m != 0.f) atomicAdd(dtab_flat + grad_off[j] + idx * dim[j] + (col - col_off[j]), g * m);
+      }
+    } else if (dcont) {
+      const int e = col - cat_width;
+      dcont[b * n_cont + e] = cont_mask ? g * cont_mask[b * n_cont + e] : g;
+    }
+  }
+}
+
+int grid_for(long n) {
+  long b = nnl_cdiv(n, kBlock);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int nnl_tab_renorm(const int64_t* xcat, float* const* tables, const int32_t* card, const int32_t* dim,
+                              const int32_t* row_off, const int32_t* row_table, int32_t* flags, int64_t bs, int32_t ncat,
+                              int32_t total_rows, float max_norm, int32_t* err_flag, void* stream) {
+  NNL_CHECK_ARG(bs >= 0 && ncat > 0 && total_rows > 0, "tab_renorm: bad sizes");
+  if (bs == 0) return NNL_OK;
+  NNL_CHECK_ARG(xcat && tables && card && dim && row_off && row_table && flags, "tab_renorm: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_TABULAR, s, 8.0 * bs * ncat);
+  hipLaunchKernelGGL(tab_mark_kernel, dim3(grid_for(bs * ncat)), dim3(kBlock), 0, s, xcat, card, row_off, flags, (long)bs, ncat,
+                     err_flag);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(tab_renorm_kernel, dim3((unsigned)nnl_cdiv((long)total_rows * 16, kBlock)), dim3(kBlock), 0, s, tables, dim,
+                     row_off, row_table, flags, total_rows, max_norm);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_tab_gather_fwd(const int64_t* xcat, const float* const* tables, const int32_t* card, const int32_t* dim,
+                                  const int32_t* col_off, const int32_t* col_table, const float* row_mask, const float* cont,
+                                  const float* cont_mask, float* out, int64_t bs, int32_t ncat, int32_t cat_width,
+                                  int32_t n_cont, int32_t ld_out, void* stream) {
+  NNL_CHECK_ARG(bs >= 0 && ncat >= 0 && cat_width >= 0 && n_cont >= 0 && ld_out >= cat_width + n_cont && ld_out > 0,
+                "tab_gather_fwd: bad sizes");
+  if (bs == 0) return NNL_OK;
+  NNL_CHECK_ARG(out && (ncat == 0 || (xcat && tables && card && dim && col_off && col_table)) && (n_cont == 0 || cont),
+                "tab_gather_fwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_TABULAR, s, (double)bs * (8.0 * ncat + 4.0 * (cat_width + n_cont) + 4.0 * ld_out));
+  hipLaunchKernelGGL(tab_gather_kernel, dim3(grid_for(bs * ld_out)), dim3(kBlock), 0, s, xcat, tables, card, dim, col_off,
+                     col_table, row_mask, cont, cont_mask, out, (long)bs, ncat, cat_width, n_cont, ld_out);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, const int32_t* dim, const int32_t* col_off,
+                                   const int32_t* col_table, const int64_t* grad_off, const float* row_mask,
+                                   const float* cont_mask, const float* dout, float* dtab_flat, int64_t dtab_elems,
+                                   float* dcont, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out,
+                                   void* stream) {
+  NNL_CHECK_ARG(bs >= 0 && ncat >= 0 && cat_width >= 0 && n_cont >= 0 && ld_out >= cat_width + n_cont && dtab_elems >= 0,
+                "tab_scatter_bwd: bad sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtab_flat && dtab_elems > 0) NNL_CHECK_HIP(hipMemsetAsync(dtab_flat, 0, sizeof(float) * dtab_elems, s));
+  if (bs == 0) return NNL_OK;
+  NNL_CHECK_ARG(dout && (ncat == 0 || (xcat && card && dim && col_off && col_table && grad_off && dtab_flat)),
+                "tab_scatter_bwd: null pointer");
+  NnlProfScope prof(NNL_PROF_TABULAR, s, (double)bs * (8.0 * ncat + 8.0 * (cat_width + n_cont)));
+  hipLaunchKernelGGL(tab_scatter_kernel, dim3(grid_for(bs * (cat_width + n_cont))), dim3(kBlock), 0, s, xcat, card, dim, col_off,
+                     col_table, grad_off, row_mask, cont_mask, dout, dtab_flat, dcont, (long)bs, ncat, cat_width, n_cont, ld_out);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}

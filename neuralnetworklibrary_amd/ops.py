@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, require_cuda, stream
 
-__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc', 'linear', 'bn_act', 'concat_pool2d']
+__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc', 'linear', 'bn_act', 'concat_pool2d', 'TabularPlan', 'tab_embed_concat', 'embedding_renorm_drop', 'retina_loss']
 
 _ERR_FLAGS = {}
 
@@ -243,3 +243,139 @@ def bn_act(bn, x, residual=None, relu=True):
 def concat_pool2d(x):
     """cat([global max pool, global avg pool], 1) -> [N, 2C, 1, 1]  (AdaptiveConcatPool2d, General/Layers.py:78-87)."""
     return torch.cat([x.amax(dim=(2, 3), keepdim=True), x.mean(dim=(2, 3), keepdim=True)], 1)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K3 tabular front end
+# ---------------------------------------------------------------------------------------------------------
+class TabularPlan:
+    """Device-side descriptor arrays for a list of embedding tables (see include/nnl.h, K3).  Rebuilt when a table
+    moves (data_ptr / device change)."""
+
+    def __init__(self, weights):
+        import numpy as np
+        dev = weights[0].device
+        self.key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights) + (str(dev),)
+        card = [int(w.shape[0]) for w in weights]
+        dim = [int(w.shape[1]) for w in weights]
+        self.ncat, self.cat_width, self.total_rows = len(weights), sum(dim), sum(card)
+        col_off = np.concatenate([[0], np.cumsum(dim)[:-1]]).astype(np.int32)
+        row_off = np.concatenate([[0], np.cumsum(card)[:-1]]).astype(np.int32)
+        sizes = [c * d for c, d in zip(card, dim)]
+        self.grad_sizes, self.shapes = sizes, [tuple(w.shape) for w in weights]
+        grad_off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        self.grad_elems = int(sum(sizes))
+        t = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(dev)
+        self.ptrs = t(np.array([w.data_ptr() for w in weights], dtype=np.int64), torch.int64)
+        self.card, self.dim = t(card, torch.int32), t(dim, torch.int32)
+        self.col_off, self.row_off, self.grad_off = t(col_off, torch.int32), t(row_off, torch.int32), t(grad_off, torch.int64)
+        self.col_table = t(np.repeat(np.arange(self.ncat), dim), torch.int32)
+        self.row_table = t(np.repeat(np.arange(self.ncat), card), torch.int32)
+        self.flags = torch.zeros(self.total_rows, dtype=torch.int32, device=dev)
+
+    @staticmethod
+    def for_weights(weights, cached=None):
+        key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights) + (str(weights[0].device),)
+        return cached if (cached is not None and cached.key == key) else TabularPlan(weights)
+
+
+class _TabEmbedConcat(torch.autograd.Function):
+    """StructuredDataNet.forward front end (reference Applications/StructuredData.py:1074-1082 + General/Layers.py:74-76)."""
+
+    @staticmethod
+    def forward(ctx, xcat, cont, row_mask, cont_mask, plan, max_norm, *weights):
+        require_cuda(xcat, cont, *weights)
+        for w in weights:
+            if not (w.is_contiguous() and w.dtype == torch.float32):
+                raise _lib.NnlError('tab_embed_concat: embedding tables must be contiguous fp32 parameters')
+        xcat = xcat.contiguous().long()
+        bs = xcat.shape[0]
+        n_cont = 0 if cont is None else cont.shape[1]
+        cont = None if cont is None else _f32c(cont)
+        row_mask = None if row_mask is None else _f32c(row_mask)
+        cont_mask = None if cont_mask is None else _f32c(cont_mask)
+        if max_norm is not None:
+            check(lib.nnl_tab_renorm(ptr(xcat), ptr(plan.ptrs), ptr(plan.card), ptr(plan.dim), ptr(plan.row_off),
+                                     ptr(plan.row_table), ptr(plan.flags), bs, plan.ncat, plan.total_rows, float(max_norm),
+                                     ptr(index_error_flag(xcat.device)), stream()))
+        ld = plan.cat_width + n_cont
+        out = torch.empty(bs, ld, dtype=torch.float32, device=xcat.device)
+        check(lib.nnl_tab_gather_fwd(ptr(xcat), ptr(plan.ptrs), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off),
+                                     ptr(plan.col_table), ptr(row_mask), ptr(cont), ptr(cont_mask), ptr(out), bs, plan.ncat,
+                                     plan.cat_width, n_cont, ld, stream()))
+        ctx.save_for_backward(xcat, row_mask, cont_mask)
+        ctx.plan, ctx.n_cont = plan, n_cont
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xcat, row_mask, cont_mask = ctx.saved_tensors
+        plan, n_cont = ctx.plan, ctx.n_cont
+        dout = _f32c(dout)
+        bs = xcat.shape[0]
+        flat = torch.empty(max(plan.grad_elems, 1), dtype=torch.float32, device=dout.device)
+        dcont = torch.empty(bs, n_cont, dtype=torch.float32, device=dout.device) if (n_cont and ctx.needs_input_grad[1]) else None
+        check(lib.nnl_tab_scatter_bwd(ptr(xcat), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off), ptr(plan.col_table),
+                                      ptr(plan.grad_off), ptr(row_mask), ptr(cont_mask), ptr(dout), ptr(flat), plan.grad_elems,
+                                      ptr(dcont), bs, plan.ncat, plan.cat_width, n_cont, dout.shape[1], stream()))
+        grads, o = [], 0
+        for n, shp in zip(plan.grad_sizes, plan.shapes):
+            grads.append(flat[o:o + n].view(shp))
+            o += n
+        return (None, dcont, None, None, None, None) + tuple(grads)
+
+
+def tab_embed_concat(xcat, weights, row_mask=None, cont=None, cont_mask=None, max_norm=None, plan=None):
+    """[bs, sum(d_j) + n_cont] = cat_j( W_j[xcat[:,j]] * row_mask[j][:,None] ) ++ cont*cont_mask, after the in-place
+    max_norm renorm of the looked-up rows.  Returns (out, plan)."""
+    plan = TabularPlan.for_weights(weights, plan)
+    return _TabEmbedConcat.apply(xcat, cont, row_mask, cont_mask, plan, max_norm, *weights), plan
+
+
+def embedding_renorm_drop(x, weight, mask, max_norm):
+    """EmbeddingDrop.forward for ONE column (General/Layers.py:74-76): emb(x) * mask.unsqueeze(1)."""
+    out, _ = tab_embed_concat(x.view(-1, 1), [weight], None if mask is None else mask.view(1, -1), None, None, max_norm)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K6 fused RetinaNet loss
+# ---------------------------------------------------------------------------------------------------------
+class _RetinaLoss(torch.autograd.Function):
+    """SSD_loss.__call__ (reference Applications/Vision.py:1620-1644 and everything below it) as one fused forward
+    kernel and one fused backward kernel; returns [total, reg_loss, clas_loss].  Gradient flows through `total`."""
+
+    @staticmethod
+    def forward(ctx, anchors, reg, clas, boxes, cats, beta, alpha, gamma):
+        require_cuda(anchors, reg, clas, boxes, cats)
+        anchors, reg, clas, boxes = _f32c(anchors), _f32c(reg), _f32c(clas), _f32c(boxes)
+        cats = cats.contiguous().long()
+        bs, A, K = clas.shape
+        M = boxes.shape[1]
+        dev = clas.device
+        state = torch.empty(bs, A, dtype=torch.int32, device=dev)
+        npos = torch.empty(bs, dtype=torch.float32, device=dev)
+        out = torch.empty(3, dtype=torch.float32, device=dev)
+        wsb = int(lib.nnl_retina_loss_workspace_bytes(bs, A))
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=dev)
+        check(lib.nnl_retina_loss_fwd(ptr(anchors), ptr(reg), ptr(clas), ptr(boxes), ptr(cats), ptr(state), ptr(npos), ptr(out),
+                                      bs, A, K, M, float(beta), float(alpha), float(gamma), ptr(ws), wsb, stream()))
+        ctx.save_for_backward(anchors, reg, clas, boxes, cats, state, npos)
+        ctx.hyper = (float(beta), float(alpha), float(gamma))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        anchors, reg, clas, boxes, cats, state, npos = ctx.saved_tensors
+        beta, alpha, gamma = ctx.hyper
+        bs, A, K = clas.shape
+        gup = _f32c(dout)[0:1].contiguous()
+        dreg, dclas = torch.empty_like(reg), torch.empty_like(clas)
+        check(lib.nnl_retina_loss_bwd(ptr(anchors), ptr(reg), ptr(clas), ptr(boxes), ptr(cats), ptr(state), ptr(npos), ptr(gup),
+                                      ptr(dreg), ptr(dclas), bs, A, K, boxes.shape[1], beta, alpha, gamma, stream()))
+        return None, dreg, dclas, None, None, None, None, None
+
+
+def retina_loss(anchors, reg, clas, boxes, cats, beta=0.5, alpha=0.25, gamma=2.0):
+    """[ (1-beta)*reg_loss + beta*clas_loss, reg_loss, clas_loss ] for a batch (see include/nnl.h, K6)."""
+    return _RetinaLoss.apply(anchors, reg, clas, boxes, cats, beta, alpha, gamma)

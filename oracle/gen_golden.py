@@ -188,7 +188,106 @@ def g6_resnet34():
     save('g6_resnet34', **out)
 
 
-GROUPS = {'g1': g1_collab, 'g5': g5_blocks, 'g6': g6_resnet34}
+def g3_tabular():
+    """G2+G3: EmbeddingDrop renorm (weight before/after, output) and StructuredDataNet (cards [20,5,4,13], n_cont 3, fc
+    [32,16,1], range [5,12], dropout 0): forward, MSE loss, all gradients, then 3 Learner.train1minibatch steps (Adam,
+    lr 1e-3, wd 1e-3), BN running stats and every parameter afterwards."""
+    L = R['General.Layers']
+    SD = R['Applications.StructuredData']
+    out = {}
+    # --- G2: single EmbeddingDrop column with rows above max_norm
+    emb = L.EmbeddingDrop(20, 5, 0.0, 1.0, 1.5)
+    synth.fill_module_(emb, seed=3)
+    with torch.no_grad():
+        emb.emb.weight.mul_(1.8)
+    x = torch.from_numpy(np.random.RandomState(11).randint(0, 20, size=12).astype(np.int64))
+    out['g2.w_before'] = A(emb.emb.weight)
+    out['g2.x'] = A(x)
+    out['g2.y'] = A(emb(x))
+    out['g2.w_after'] = A(emb.emb.weight)
+    # --- G3
+    cards, n_cont, bs = [20, 5, 4, 13], 3, 64
+    labels = [{i: i for i in range(c)} for c in cards]
+    net = SD.StructuredDataNet('cont', len(cards), n_cont, labels, [32, 16, 1], output_range=[5, 12])
+    synth.fill_module_(net, seed=4)
+    rs = np.random.RandomState(12)
+    batches = []
+    for i in range(3):
+        xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=bs) for c in cards], 1).astype(np.int64))
+        xcont = torch.from_numpy(rs.standard_normal((bs, n_cont)).astype(np.float32) * 2 + 1)
+        y = torch.from_numpy((5 + 7 * rs.rand(bs)).astype(np.float32))
+        batches.append(([xcat, xcont], y))
+        out['xcat%d' % i], out['xcont%d' % i], out['y%d' % i] = A(xcat), A(xcont), A(y)
+    out['cards'], out['n_cont'] = np.array(cards), n_cont
+    out['emb_dims'] = np.array([e.emb.weight.shape[1] for e in net.embeddings])
+    net.train()
+    (xcat, xcont), y = batches[0]
+    pred = net(xcat, xcont)
+    loss = torch.nn.MSELoss()(pred, y)
+    loss.backward()
+    out['pred0'], out['loss0'] = A(pred), A(loss)
+    for n, p in net.named_parameters():
+        out['grad0.' + n] = A(p.grad)
+    for n, b in net.named_buffers():
+        out['buf0.' + n] = A(b)
+    for n, p in net.named_parameters():
+        out['after_fwd0.' + n] = A(p)                     # embeddings were renormed in place by the forward
+    # fresh net, 3 real Learner steps
+    net = SD.StructuredDataNet('cont', len(cards), n_cont, labels, [32, 16, 1], output_range=[5, 12])
+    synth.fill_module_(net, seed=4)
+    data = FakeData(batches, batches, bs, 'cont')
+    learner = Learner('/tmp/nnl_golden_g3', data, net, optimizer='Adam')
+    learner.init_optimizer(wd=1e-3)
+    net.train()
+    out['step_losses'] = np.array([learner.train1minibatch(xb, yb, [1e-3, 3e-3]) for xb, yb in batches], dtype=np.float64)
+    for n, p in net.state_dict().items():
+        out['after3.' + n] = A(p)
+    net.eval()
+    out['eval_pred0'] = A(net(*batches[0][0]))
+    save('g3_tabular', **out)
+
+
+def g8_detection():
+    """G8: anchors for 64x64 and 512x512 (shape, first/last rows, checksums); SSD_loss (beta .5, alpha .25, gamma 2) and
+    its gradients wrt reg / clas on 3 images with {0, 3, 2} boxes, K=5, on the 64x64 anchor set; per-image pieces from
+    match_anchors_objects / focal_loss_retina / smoothL1_loss_retina."""
+    RN = R['Applications.VisionModels.retinanet']
+    V = R['Applications.Vision']
+    out = {}
+    gen = RN.AnchorGenerator()
+    for sz in [64, 512]:
+        a = A(gen(torch.zeros(1, 3, sz, sz)))
+        out['anchors%d.shape' % sz] = np.array(a.shape)
+        out['anchors%d.head' % sz], out['anchors%d.tail' % sz] = a[:40].copy(), a[-40:].copy()
+        out['anchors%d.sum' % sz] = a.astype(np.float64).sum(0)
+        out['anchors%d.abs_sum' % sz] = np.abs(a.astype(np.float64)).sum(0)
+    anchors = gen(torch.zeros(1, 3, 64, 64))
+    Na, K, bs, M = len(anchors), 5, 3, 4
+    rs = np.random.RandomState(21)
+    boxes = -np.ones((bs, M, 4), np.float32); cats = -np.ones((bs, M), np.int64)
+    # image 0: no objects; image 1: 3 objects; image 2: 2 objects (one tiny: exercises the w,h >= 1 clamp)
+    boxes[1, :3] = [[4, 6, 40, 44], [20, 10, 60, 34], [30, 30, 46, 62]]; cats[1, :3] = [2, 0, 4]
+    boxes[2, :2] = [[10.2, 12.7, 10.9, 13.1], [0, 0, 33, 31]]; cats[2, :2] = [1, 3]
+    reg = torch.from_numpy(rs.standard_normal((bs, Na, 4)).astype(np.float32) * 0.5).requires_grad_(True)
+    clas = torch.from_numpy(rs.uniform(0, 1, (bs, Na, K)).astype(np.float32))
+    clas.view(-1)[::97] = 1e-6; clas.view(-1)[::89] = 1 - 1e-6          # values outside the clamp range
+    clas.requires_grad_(True)
+    B, Cc = torch.from_numpy(boxes), torch.from_numpy(cats)
+    lf = V.SSD_loss(0.5, 0.25, 2.0)
+    loss = lf([anchors, reg, clas], [B, Cc])
+    loss.backward()
+    out.update({'boxes': boxes, 'cats': cats, 'reg': A(reg), 'clas': A(clas), 'loss': A(loss), 'reg_loss': A(lf.reg_loss),
+                'clas_loss': A(lf.clas_loss), 'dreg': A(reg.grad), 'dclas': A(clas.grad)})
+    for i in range(bs):
+        bb, cc = B[i][Cc[i] >= 0], Cc[i][Cc[i] >= 0]
+        pos, neg, matches = V.match_anchors_objects(bb, anchors)
+        out['img%d.pos' % i], out['img%d.neg' % i], out['img%d.matches' % i] = A(pos), A(neg), A(matches)
+        r, c = V.ssd1(anchors, bb, cc, reg[i].detach(), clas[i].detach())
+        out['img%d.reg_loss' % i], out['img%d.clas_loss' % i] = A(r), A(c)
+    save('g8_detection', **out)
+
+
+GROUPS = {'g1': g1_collab, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)

@@ -90,3 +90,89 @@ def optimizer_step(params, grads, state, lrs, wds, kind, momentum=0.9, betas=(0.
                 p.addcdiv_(state.m[i], denom, value=-lrs[i] / bc1)
             else:
                 raise ValueError(kind)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# K6  detection loss — Applications/Vision.py:234-256, 1474-1511, 1513-1530, 1532-1566, 1568-1605, 1620-1644
+# ---------------------------------------------------------------------------------------------------------
+def jaccard(B1, B2):
+    "IoU matrix [n,m] of min-max boxes, no +1 (Vision.py:234-256)"
+    a1 = (B1[:, 2] - B1[:, 0]) * (B1[:, 3] - B1[:, 1])
+    a2 = (B2[:, 2] - B2[:, 0]) * (B2[:, 3] - B2[:, 1])
+    b1, b2 = B1.unsqueeze(1), B2.unsqueeze(0)
+    iw = (torch.min(b1[:, :, 2], b2[:, :, 2]) - torch.max(b1[:, :, 0], b2[:, :, 0])).clamp(min=0)
+    ih = (torch.min(b1[:, :, 3], b2[:, :, 3]) - torch.max(b1[:, :, 1], b2[:, :, 1])).clamp(min=0)
+    inter = iw * ih
+    return inter / (a1.unsqueeze(1) + a2.unsqueeze(0) - inter)
+
+
+def match_anchors_objects(objects, anchors, pos_thresh=0.5, neg_thresh=0.4):
+    "state per anchor: matched object index (>=0) if max IoU > .5, -1 if < .4, -2 otherwise (Vision.py:1474-1511)"
+    N = len(anchors)
+    if len(objects) == 0:
+        return torch.full((N,), -1, dtype=torch.long)
+    mx, arg = torch.max(jaccard(objects, anchors), dim=0)
+    state = torch.full((N,), -2, dtype=torch.long)
+    state[mx < neg_thresh] = -1
+    state[mx > pos_thresh] = arg[mx > pos_thresh]
+    return state
+
+
+def focal_loss_retina(pred, target, alpha=0.25, gamma=2.0):
+    "Vision.py:1513-1530"
+    p = pred.clamp(1e-4, 1.0 - 1e-4)
+    pt = p * target + (1 - p) * (1 - target)
+    w = (alpha * target + (1 - alpha) * (1 - target)) * (1 - pt).pow(gamma)
+    losses = -w * (target * torch.log(p) + (1 - target) * torch.log(1 - p))
+    return losses.sum() / target.sum().clamp(min=1)
+
+
+def smoothL1_loss_retina(anchs, pred_shift, target):
+    "Vision.py:1532-1566"
+    aw, ah = anchs[:, 2] - anchs[:, 0], anchs[:, 3] - anchs[:, 1]
+    ax, ay = anchs[:, 0] + 0.5 * aw, anchs[:, 1] + 0.5 * ah
+    tw, th = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1]
+    tx, ty = target[:, 0] + 0.5 * tw, target[:, 1] + 0.5 * th
+    tw, th = tw.clamp(min=1), th.clamp(min=1)
+    true = torch.stack(((tx - ax) / aw, (ty - ay) / ah, torch.log(tw / aw), torch.log(th / ah))).t()
+    true = true / torch.tensor([[0.1, 0.1, 0.2, 0.2]])
+    diff = torch.abs(true - pred_shift)
+    losses = 0.5 * 9 * diff.pow(2) * (diff < 1 / 9).float() + (diff - 0.5 / 9) * (diff >= 1 / 9).float()
+    return losses.mean()
+
+
+def ssd_loss(anchors, reg, clas, BBoxes, Cats, beta=0.5, alpha=0.25, gamma=2.0):
+    """(total, reg_loss, clas_loss) of a batch: per image strip the -1 padding, match, build the one-hot targets of
+    the positive anchors, focal over pos+neg anchors, smooth-L1 over pos anchors; batch means (Vision.py:1568-1644)."""
+    bs, K = len(BBoxes), clas.shape[2]
+    reg_loss, clas_loss = torch.zeros(()), torch.zeros(())
+    for i in range(bs):
+        keep = Cats[i] >= 0
+        boxes, cats = BBoxes[i][keep], Cats[i][keep]
+        state = match_anchors_objects(boxes, anchors)
+        pos, used = state >= 0, state != -2
+        targ = torch.zeros(len(anchors), K)
+        if pos.any():
+            targ[pos.nonzero().view(-1), cats[state[pos]]] = 1
+        clas_loss = clas_loss + focal_loss_retina(clas[i][used], targ[used], alpha, gamma)
+        if pos.any():
+            reg_loss = reg_loss + smoothL1_loss_retina(anchors[pos], reg[i][pos], boxes[state[pos]])
+    reg_loss, clas_loss = reg_loss / bs, clas_loss / bs
+    return (1 - beta) * reg_loss + beta * clas_loss, reg_loss, clas_loss
+
+
+def anchors_for(H, W, ratios=(0.5, 1, 2), scales=(2 ** 0, 2 ** (1 / 3), 2 ** (2 / 3))):
+    """float32 [sum_l H_l*W_l*9, 4] anchors of pyramid levels 3..7: stride 2^l, base size 2^(l+2), 3 ratios x 3 scales
+    (ratio-major), centres (i+0.5)*stride, cell-major / anchor-minor order (retinanet.py:439-495; numpy fp64 -> fp32)."""
+    S = np.tile(np.array(scales), len(ratios))
+    Rt = np.repeat(np.array(ratios), len(scales))
+    Hs, Ws = S / np.sqrt(Rt), S * np.sqrt(Rt)
+    base = np.array([-Ws / 2, -Hs / 2, Ws / 2, Hs / 2]).T
+    out = []
+    for lvl in [3, 4, 5, 6, 7]:
+        stride, size = 2 ** lvl, 2 ** (lvl + 2)
+        gh, gw = (H + stride - 1) // stride, (W + stride - 1) // stride
+        sx, sy = np.meshgrid((np.arange(gw) + 0.5) * stride, (np.arange(gh) + 0.5) * stride)
+        shifts = np.stack([sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()], 1)
+        out.append((shifts[:, None, :] + (size * base)[None, :, :]).reshape(-1, 4))
+    return torch.from_numpy(np.concatenate(out).astype(np.float32))

@@ -1,0 +1,121 @@
+"""Detection loss (K6) and anchors: oracle pinned to the reference golden G8 on CPU; fused HIP kernel vs golden and
+vs the oracle at the BASELINE size (512x512 -> 49 104 anchors, K=20, bs=16) on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, assert_close, load_golden
+from oracle import reference_math as RM
+
+DEV = 'cuda'
+
+
+def check_anchors(make, g):
+    for sz in [64, 512]:
+        a = make(sz).detach().cpu().numpy()
+        assert list(a.shape) == list(g['anchors%d.shape' % sz])
+        np.testing.assert_array_equal(a[:40], g['anchors%d.head' % sz])          # bit-exact
+        np.testing.assert_array_equal(a[-40:], g['anchors%d.tail' % sz])
+        np.testing.assert_allclose(a.astype(np.float64).sum(0), g['anchors%d.sum' % sz], rtol=0, atol=0)
+        np.testing.assert_allclose(np.abs(a.astype(np.float64)).sum(0), g['anchors%d.abs_sum' % sz], rtol=0, atol=0)
+    assert g['anchors512.shape'][0] == 49104
+
+
+def state_from_golden(g, i, N):
+    st = np.full(N, -2, dtype=np.int64)
+    st[g['img%d.neg' % i]] = -1
+    pos = g['img%d.pos' % i]
+    st[pos] = g['img%d.matches' % i][pos]
+    return st
+
+
+def test_g8_anchors_oracle():
+    check_anchors(lambda sz: RM.anchors_for(sz, sz), load_golden('g8_detection'))
+
+
+def test_g8_loss_oracle():
+    g = load_golden('g8_detection')
+    anchors = RM.anchors_for(64, 64)
+    reg, clas = T(g['reg']).requires_grad_(True), T(g['clas']).requires_grad_(True)
+    B, C = T(g['boxes']), T(g['cats'])
+    for i in range(len(B)):
+        st = RM.match_anchors_objects(B[i][C[i] >= 0], anchors)
+        np.testing.assert_array_equal(st.numpy(), state_from_golden(g, i, len(anchors)))
+    total, r, c = RM.ssd_loss(anchors, reg, clas, B, C, 0.5, 0.25, 2.0)
+    assert_close(total, g['loss'], 1e-6, 1e-7, 'loss')
+    assert_close(r, g['reg_loss'], 1e-6, 1e-7, 'reg')
+    assert_close(c, g['clas_loss'], 1e-6, 1e-7, 'clas')
+    total.backward()
+    assert_close(reg.grad, g['dreg'], 1e-5, 1e-9, 'dreg')
+    assert_close(clas.grad, g['dclas'], 1e-5, 1e-9, 'dclas')
+
+
+@pytest.mark.gpu
+def test_g8_anchors_hip_side():
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import AnchorGenerator
+    gen = AnchorGenerator()
+    check_anchors(lambda sz: gen(torch.zeros(1, 3, sz, sz, device=DEV)), load_golden('g8_detection'))
+    assert gen(torch.zeros(1, 3, 64, 64, device=DEV)) is gen(torch.zeros(2, 3, 64, 64, device=DEV))     # cached on device
+
+
+@pytest.mark.gpu
+def test_g8_loss_hip():
+    from neuralnetworklibrary_amd.Applications.Vision import SSD_loss, ssd1
+    g = load_golden('g8_detection')
+    anchors = RM.anchors_for(64, 64).to(DEV)
+    reg, clas = T(g['reg'], DEV).requires_grad_(True), T(g['clas'], DEV).requires_grad_(True)
+    B, C = T(g['boxes'], DEV), T(g['cats'], DEV)
+    lf = SSD_loss(0.5, 0.25, 2.0)
+    loss = lf([anchors, reg, clas], [B, C])
+    assert_close(loss, g['loss'], 1e-5, 1e-7, 'loss')
+    assert_close(lf.reg_loss, g['reg_loss'], 1e-5, 1e-7, 'reg')
+    assert_close(lf.clas_loss, g['clas_loss'], 1e-5, 1e-7, 'clas')
+    loss.backward()
+    assert_close(reg.grad, g['dreg'], 1e-4, 1e-9, 'dreg')
+    assert_close(clas.grad, g['dclas'], 1e-4, 1e-8, 'dclas')
+    for i in range(len(B)):                                  # per-image API (ssd1) incl. the image without objects
+        keep = C[i] >= 0
+        r, c = ssd1(anchors, B[i][keep], C[i][keep], reg[i].detach(), clas[i].detach())
+        assert_close(r, g['img%d.reg_loss' % i], 1e-5, 1e-7, 'img reg')
+        assert_close(c, g['img%d.clas_loss' % i], 1e-5, 1e-7, 'img clas')
+
+
+@pytest.mark.gpu
+def test_matching_state_bit_exact():
+    """The kernel's pos / neg / ignore decision per anchor must equal the reference's: it thresholds the same IEEE ops."""
+    from neuralnetworklibrary_amd import ops
+    g = load_golden('g8_detection')
+    anchors = RM.anchors_for(64, 64).to(DEV)
+    reg, clas, B, C = T(g['reg'], DEV), T(g['clas'], DEV), T(g['boxes'], DEV), T(g['cats'], DEV)
+    f = ops._RetinaLoss
+    ctx = type('C', (), {'save_for_backward': lambda self, *a: setattr(self, 'saved', a)})()
+    f.forward(ctx, anchors, reg, clas, B, C, 0.5, 0.25, 2.0)
+    state = ctx.saved[5].cpu().numpy()
+    for i in range(len(B)):
+        np.testing.assert_array_equal(state[i], state_from_golden(g, i, anchors.shape[0]))
+
+
+@pytest.mark.gpu
+def test_full_size_vs_oracle():
+    """BASELINE config 5 loss shapes: 512x512 -> 49 104 anchors, K=20, bs=16, 1..8 boxes per image."""
+    from neuralnetworklibrary_amd import ops
+    rs = np.random.RandomState(5)
+    bs, K, M = 16, 20, 8
+    anchors = RM.anchors_for(512, 512)
+    A = len(anchors)
+    boxes = -np.ones((bs, M, 4), np.float32); cats = -np.ones((bs, M), np.int64)
+    for i in range(bs):
+        m = rs.randint(1, M + 1)
+        xy = rs.uniform(0, 300, (m, 2)); wh = rs.uniform(30, 210, (m, 2))
+        boxes[i, :m] = np.concatenate([xy, xy + wh], 1); cats[i, :m] = rs.randint(0, K, m)
+    reg = torch.from_numpy(rs.standard_normal((bs, A, 4)).astype(np.float32) * 0.3)
+    clas = torch.from_numpy(rs.uniform(0.001, 0.2, (bs, A, K)).astype(np.float32))
+    rc, cc = reg.clone().requires_grad_(True), clas.clone().requires_grad_(True)
+    total, r, c = RM.ssd_loss(anchors, rc, cc, torch.from_numpy(boxes), torch.from_numpy(cats))
+    total.backward()
+    rg, cg = reg.to(DEV).requires_grad_(True), clas.to(DEV).requires_grad_(True)
+    out = ops.retina_loss(anchors.to(DEV), rg, cg, torch.from_numpy(boxes).to(DEV), torch.from_numpy(cats).to(DEV))
+    out[0].backward()
+    assert_close(out, torch.stack([total, r, c]), 1e-4, 1e-6, 'losses')
+    assert_close(rg.grad, rc.grad, 1e-4, 1e-10, 'dreg')
+    assert_close(cg.grad, cc.grad, 1e-4, 1e-9, 'dclas')

@@ -1,0 +1,162 @@
+"""Tabular head (K3 + MLP): oracle pinned to reference goldens G2/G3 on CPU; HIP product vs goldens/oracle on GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import T, assert_close, load_golden
+from oracle import reference_math as RM
+from oracle import reference_nets as RNets
+from oracle import synth
+
+DEV = 'cuda'
+
+
+def make_oracle(g, seed=4):
+    cards, dims = [int(c) for c in g['cards']], [int(d) for d in g['emb_dims']]
+    net = RNets.StructuredDataNet('cont', list(zip(cards, dims)), int(g['n_cont']), [32, 16, 1], output_range=[5, 12])
+    return synth.fill_module_(net, seed=seed)
+
+
+def make_product(g, seed=4):
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    cards = [int(c) for c in g['cards']]
+    labels = [{i: i for i in range(c)} for c in cards]
+    net = StructuredDataNet('cont', len(cards), int(g['n_cont']), labels, [32, 16, 1], output_range=[5, 12])
+    assert [e.emb.weight.shape[1] for e in net.embeddings] == [int(d) for d in g['emb_dims']]
+    return synth.fill_module_(net, seed=seed)
+
+
+def group_of(name):
+    return 1 if name.startswith('head') else 0
+
+
+def check_forward_backward(net, g, dev, rtol, call):
+    net.train()
+    xcat, xcont, y = T(g['xcat0'], dev), T(g['xcont0'], dev), T(g['y0'], dev)
+    pred = call(net, xcat, xcont)
+    assert_close(pred, g['pred0'], rtol, 1e-5, 'pred')
+    loss = nn.MSELoss()(pred, y)
+    assert_close(loss, g['loss0'], rtol, 1e-6, 'loss')
+    loss.backward()
+    for n, p in net.named_parameters():
+        ref = g['grad0.' + n]
+        assert_close(p.grad, ref, 1e-3, 1e-5 * max(np.abs(ref).max(), 1e-3), 'grad ' + n)
+        assert_close(p, g['after_fwd0.' + n], 1e-6, 1e-7, 'param after forward (renorm) ' + n)
+    for n, b in net.named_buffers():
+        assert_close(b, g['buf0.' + n], 1e-5, 1e-6, 'buffer ' + n)
+
+
+def test_g2_embeddingdrop_oracle():
+    g = load_golden('g3_tabular')
+    emb = RNets.EmbeddingDrop(20, 5, 0.0, 1.0, 1.5)
+    with torch.no_grad():
+        emb.emb.weight.copy_(T(g['g2.w_before']))
+    y = emb(T(g['g2.x']))
+    assert_close(y, g['g2.y'], 1e-6, 1e-7, 'y')
+    assert_close(emb.emb.weight, g['g2.w_after'], 1e-6, 1e-7, 'renormed weight')
+    changed = np.abs(g['g2.w_after'] - g['g2.w_before']).sum(1) > 0
+    assert changed.any() and not changed.all()                     # only touched rows above max_norm moved
+    assert set(np.nonzero(changed)[0]) <= set(g['g2.x'].tolist())
+
+
+def test_g3_oracle_forward_backward_and_steps():
+    g = load_golden('g3_tabular')
+    check_forward_backward(make_oracle(g), g, 'cpu', 1e-5, lambda n, a, b: n(a, b))
+    # restated 3 x train1minibatch: Adam(lr [1e-3,3e-3] per layer group), decoupled wd 1e-3 on reg + bn groups
+    net = make_oracle(g).train()
+    names = [n for n, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    state = RM.OptimState(params)
+    lrs = [[1e-3, 3e-3][group_of(n)] for n in names]
+    losses = []
+    for i in range(3):
+        for p in params:
+            p.grad = None
+        loss = nn.MSELoss()(net(T(g['xcat%d' % i]), T(g['xcont%d' % i])), T(g['y%d' % i]))
+        loss.backward()
+        losses.append(loss.item())
+        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [1e-3] * len(params), 'adam')
+    assert_close(np.array(losses), g['step_losses'], 1e-5, 1e-7, 'step losses')
+    for n, v in net.state_dict().items():
+        assert_close(v, g['after3.' + n], 1e-4, 1e-6, 'after3 ' + n)
+    net.eval()
+    assert_close(net(T(g['xcat0']), T(g['xcont0'])), g['eval_pred0'], 1e-4, 1e-5, 'eval pred')
+
+
+@pytest.mark.gpu
+def test_g2_embeddingdrop_hip():
+    from neuralnetworklibrary_amd.General.Layers import EmbeddingDrop
+    g = load_golden('g3_tabular')
+    emb = EmbeddingDrop(20, 5, 0.0, 1.0, 1.5)
+    with torch.no_grad():
+        emb.emb.weight.copy_(T(g['g2.w_before']))
+    emb = emb.to(DEV)
+    y = emb(T(g['g2.x'], DEV))
+    assert_close(y, g['g2.y'], 1e-6, 1e-7, 'y')
+    assert_close(emb.emb.weight, g['g2.w_after'], 1e-6, 1e-7, 'renormed weight')
+    untouched = np.abs(g['g2.w_after'] - g['g2.w_before']).sum(1) == 0
+    assert torch.equal(emb.emb.weight.cpu()[untouched], T(g['g2.w_before'])[untouched])     # bit-exact untouched rows
+
+
+@pytest.mark.gpu
+def test_g3_hip_forward_backward():
+    g = load_golden('g3_tabular')
+    check_forward_backward(make_product(g).to(DEV), g, DEV, 1e-4, lambda n, a, b: n(a, b))
+
+
+@pytest.mark.gpu
+def test_g3_hip_learner_steps():
+    from neuralnetworklibrary_amd.General.Learner import Learner
+
+    class D:
+        bs, target_type = 64, 'cont'
+    g = load_golden('g3_tabular')
+    net = make_product(g).to(DEV)
+    batches = [([T(g['xcat%d' % i], DEV), T(g['xcont%d' % i], DEV)], T(g['y%d' % i], DEV)) for i in range(3)]
+    d = D(); d.train_dl = batches; d.val_dl = batches
+    learner = Learner('/tmp/nnl_test_g3', d, net, optimizer='Adam')
+    learner.init_optimizer(wd=1e-3)
+    net.train()
+    losses = [learner.train1minibatch(xb, yb, [1e-3, 3e-3]) for xb, yb in batches]
+    assert_close(np.array(losses), g['step_losses'], 1e-4, 1e-6, 'step losses')
+    for n, v in net.state_dict().items():
+        assert_close(v, g['after3.' + n], 2e-3, 2e-5, 'after3 ' + n)       # Adam's 1/sqrt(v) amplifies 1e-6 grad noise early on
+    net.eval()
+    assert_close(net(*batches[0][0]), g['eval_pred0'], 1e-3, 1e-4, 'eval pred')
+
+
+@pytest.mark.gpu
+def test_rossmann_shape_with_dropout_masks_vs_oracle():
+    """BASELINE config 3 shapes (bs 1024, 32 columns, 14 cont, fc [1000,500,1]) with injected dropout masks."""
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    from neuralnetworklibrary_amd import ops
+    cards = [1116, 5, 4, 13, 53, 13, 4, 8, 32, 23, 27, 24, 28, 9, 5, 5] + [10] * 16
+    dims = [RNets.embedding_dim(c) for c in cards]
+    labels = [{i: i for i in range(c)} for c in cards]
+    bs, n_cont = 1024, 14
+    prod = StructuredDataNet('cont', 32, n_cont, labels, [1000, 500, 1], output_range=[5, 12], dropout_levels=(0.04, 0.04, [0, 0., 0.]))
+    orac = RNets.StructuredDataNet('cont', list(zip(cards, dims)), n_cont, [1000, 500, 1], output_range=[5, 12])
+    synth.fill_module_(prod, 9); synth.fill_module_(orac, 9)
+    assert sum(dims) + n_cont == prod.head[0].lins[0].lin.in_features
+    rs = np.random.RandomState(1)
+    xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=bs) for c in cards], 1).astype(np.int64))
+    xcont = torch.from_numpy(rs.standard_normal((bs, n_cont)).astype(np.float32))
+    y = torch.from_numpy((5 + 7 * rs.rand(bs)).astype(np.float32))
+    row_masks = torch.from_numpy((rs.rand(32, bs) > 0.04).astype(np.float32) / 0.96)
+    cont_mask = torch.from_numpy((rs.rand(bs, n_cont) > 0.04).astype(np.float32) / 0.96)
+    # oracle: cont dropout mask applied by hand (its nn.Dropout has p=0)
+    orac.train()
+    cat = torch.cat([e(xcat[:, i], row_masks[i]) for i, e in enumerate(orac.embeddings)], 1)
+    ref = orac.head(torch.cat([cat, orac.cont_bn(xcont) * cont_mask], 1))
+    lref = nn.MSELoss()(ref, y); lref.backward()
+    prod = prod.to(DEV).train()
+    prod.inject_masks(row_masks.to(DEV), cont_mask.to(DEV))
+    out = prod(xcat.to(DEV), xcont.to(DEV))
+    lout = nn.MSELoss()(out, y.to(DEV)); lout.backward()
+    ops.raise_if_index_error()
+    assert_close(out, ref, 1e-4, 1e-4, 'pred')
+    assert_close(lout, lref, 1e-4, 1e-6, 'loss')
+    for (n, p), (_, q) in zip(prod.named_parameters(), orac.named_parameters()):
+        assert_close(p.grad, q.grad, 1e-3, 1e-4 * max(q.grad.abs().max().item(), 1e-6), 'grad ' + n)
+        assert_close(p, q, 1e-6, 1e-7, 'renormed ' + n)

@@ -76,4 +76,4 @@ def test_g6_resnet34_hip_learner_step_bn_frozen():
     abs_sums = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()])
     sums = np.array([p.double().sum().item() for _, p in net.named_parameters()])
     assert_close(abs_sums, g['frozen.after.abs_sums'], 1e-6, 1e-8, 'abs sums after step')
-    assert_close(sums, g['frozen.after.sums'], 1e-5, 1e-5, 'sums after step')
+    assert_close(sums, g['frozen.after.sums'], 1e-4, 1e-5 * np.abs(g['frozen.after.abs_sums']).max(), 'sums after step')
