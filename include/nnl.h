@@ -158,6 +158,39 @@ int nnl_retina_loss_bwd(const float* anchors, const float* reg, const float* cla
                         float* dreg, float* dclas, int64_t bs, int64_t A, int64_t K, int64_t M, float beta,
                         float alpha, float gamma, void* stream);
 
+/* ---- K5: recurrence of one weight-dropped LSTM layer --------------------------------------------------------
+ * Replaces nn.LSTM(num_layers=1) as called by WeightDropLSTM1.forward (Applications/Text.py:495-513) inside
+ * LSTM_Encoder.forward (:543-548): gates_t = gx_t + h_{t-1} W_hh^T, c_t = s(f) c_{t-1} + s(i) tanh(g),
+ * h_t = s(o) tanh(c_t), gate order i,f,g,o (torch).  gx [T,B,4H] = x_t W_ih^T + b_ih + b_hh for all t (one big
+ * GEMM done by the caller with nnl_conv2d_fwd as a 1x1 conv); w_hh_pad [4H, Hp] = (dropped) W_hh with rows
+ * zero-padded to Hp = ceil4(H); h0, c0 [B,H].  Outputs y [T,B,H] (h_t), cy [T,B,H] (c_t) and gates [T,B,4H]
+ * (ACTIVATED i,f,g,o) — the last two are saved for backward. */
+size_t nnl_lstm_workspace_bytes(int64_t B, int64_t H);
+int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
+                 float* gates, int64_t T, int64_t B, int64_t H, void* workspace, size_t workspace_bytes, void* stream);
+/* BPTT: dy [T,B,H] (may be NULL), dhT / dcT [B,H] (may be NULL = 0), w_hh_t [H,4H] = W_hh^T.
+ * Outputs dgates [T,B,4H] (gradient of the PRE-activation gates = d gx; the caller derives dW_ih, dW_hh, db, dx from
+ * it with the GEMM entry points), dh0, dc0 [B,H]. */
+int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy,
+                 const float* c0, const float* w_hh_t, float* dgates, float* dh0, float* dc0, int64_t T, int64_t B,
+                 int64_t H, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- K5b: embedding with per-vocabulary-row dropout mask, fused softmax + cross-entropy -----------------------
+ * nnl_embedding_rowmask_*: EmbeddingDropout.forward, F.embedding(x, W * mask[V,1], pad) (Text.py:465-475):
+ * out[i,:] = W[x[i],:] * rowmask[x[i]] (rowmask NULL = ones); backward zero-fills dW [V,D] and scatter-adds
+ * dout[i,:]*rowmask[x[i]] except for x[i] == padding_idx (pass -1 for none). */
+int nnl_embedding_rowmask_fwd(const int64_t* x, const float* W, const float* rowmask, float* out, int64_t n,
+                              int64_t V, int64_t D, int32_t* err_flag, void* stream);
+int nnl_embedding_rowmask_bwd(const int64_t* x, const float* rowmask, const float* dout, float* dW, int64_t n,
+                              int64_t V, int64_t D, int64_t padding_idx, void* stream);
+/* F.cross_entropy(logits [rows,V], target [rows], reduction='mean') (Text.py:773; also nn.CrossEntropyLoss of
+ * General/Learner.py:20): lse[r] = logsumexp, loss_rows[r] = lse[r] - logits[r,target[r]], *loss_mean = mean.
+ * Backward: dlogits = (softmax - onehot) * (*grad_out) / rows. */
+int nnl_softmax_ce_fwd(const float* logits, const int64_t* target, float* lse, float* loss_rows, float* loss_mean,
+                       int64_t rows, int64_t V, int32_t* err_flag, void* stream);
+int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
+                       float* dlogits, int64_t rows, int64_t V, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,51 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
 
 }  // namespace
 
+int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* bias, const float* add, int M, int N,
+                         int K, int relu, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 4 != 0) return nnl_set_error(NNL_ERR_INVALID_ARG, "gemm_nt: bad sizes");
+  IgemmRowkParams p{};
+  p.a = a; p.b = b; p.y = y; p.bias = bias; p.add = add;
+  p.N = M; p.H = 1; p.W = 1; p.C = K; p.P = 1; p.Q = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+  p.M = M; p.Nc = N; p.Kg = K; p.relu = relu;
+  return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
+}
+
+size_t nnl_internal_gemm_tn_workspace_bytes(int Mc, int Nc, long Kp) {
+  const WgradPlan pl = plan_wgrad(Mc, Nc, Kp);
+  return pl.splits > 1 ? (size_t)pl.splits * Mc * Nc * sizeof(float) : 0;
+}
+
+int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int Nc, long Kp, void* ws, size_t ws_bytes,
+                         hipStream_t s) {
+  if (Mc <= 0 || Nc <= 0 || Kp <= 0 || Mc % 4 != 0 || Nc % 4 != 0) return nnl_set_error(NNL_ERR_INVALID_ARG, "gemm_tn: bad sizes");
+  IgemmKmajorParams p{};
+  p.a = a; p.b = b;
+  p.N = (int)Kp; p.H = 1; p.W = 1; p.C = Nc; p.P = 1; p.Q = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
+  p.Mc = Mc; p.Nc = Nc; p.Kp = Kp;
+  const WgradPlan pl = plan_wgrad(Mc, Nc, Kp);
+  p.grid_m = pl.grid_m; p.grid_n = pl.grid_n; p.splits = pl.splits; p.k_per_split = pl.k_per_split;
+  const size_t need = nnl_internal_gemm_tn_workspace_bytes(Mc, Nc, Kp);
+  if (need > 0 && (ws == nullptr || ws_bytes < need)) return nnl_set_error(NNL_ERR_WORKSPACE, "gemm_tn: workspace too small");
+  p.y = pl.splits > 1 ? (float*)ws : y;
+  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
+  if (pl.bm == 128 && pl.bn == 128)
+    hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
+  else if (pl.bm == 128)
+    hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
+  NNL_CHECK_LAUNCH();
+  if (pl.splits > 1) {
+    const long n4 = (long)Mc * Nc / 4;
+    int blocks = (int)nnl_cdiv(n4, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, y, n4, pl.splits);
+    NNL_CHECK_LAUNCH();
+  }
+  return NNL_OK;
+}
+
 extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
                               int relu, void* stream) {
   int st = check_geom(g, "conv2d_fwd");

@@ -26,6 +26,7 @@ struct IgemmRowkParams {
   const float* b;      // [Nc][Kg] row-major (k contiguous)
   float* y;            // [M][Nc] row-major
   const float* bias;   // [Nc] or null
+  const float* add;    // [M][Nc] addend (same layout as y) or null: y = acc + bias + add
   int N, H, W, C;      // dims of the A-source tensor
   int P, Q;            // spatial dims enumerated by GEMM rows: M = N*P*Q
   int R, S, stride, pad;
@@ -46,6 +47,15 @@ struct IgemmKmajorParams {
   int splits, k_per_split;   // k_per_split multiple of BK
   int grid_m, grid_n;
 };
+
+// Plain NT GEMM on the igemm_rowk kernel (defined in conv2d.hip): y[M][N] = a[M][K] * b[N][K]^T (+bias[N]) (+add[M][N])
+// (ReLU).  K % 4 == 0.  Used by the per-timestep recurrent GEMMs of the LSTM (lstm.hip).
+int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* bias, const float* add, int M, int N,
+                         int K, int relu, hipStream_t s);
+// y[Mc][Nc] = sum_k a[k][Mc] * b[k][Nc]  (both k-major; Mc % 4 == 0, Nc % 4 == 0); split-K workspace as for wgrad.
+size_t nnl_internal_gemm_tn_workspace_bytes(int Mc, int Nc, long Kp);
+int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int Nc, long Kp, void* ws, size_t ws_bytes,
+                         hipStream_t s);
 
 // bijective XCD-aware remap: blocks that share an XCD (equal bid % 8) get a contiguous range of logical ids
 __device__ __forceinline__ int nnl_xcd_remap(int bid, int nblk) {

@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void igemm_rowk_kernel(const IgemmRowkParams p
         const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
         if (cok && row < p.M) {
           float v = acc[i][j][e] + bv;
+          if (p.add) v += p.add[(long)row * p.Nc + col];
           if (p.relu) v = fmaxf(v, 0.f);
           p.y[(long)row * p.Nc + col] = v;
         }

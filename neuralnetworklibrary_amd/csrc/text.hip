@@ -1,0 +1,189 @@
+// K5b — language-model side kernels (Applications/Text.py):
+//  * embedding gather with a per-vocabulary-row dropout mask (EmbeddingDropout.forward :465-475:
+//    F.embedding(x, W * mask[V,1], pad)) and its dense scatter-add backward (padding row gets no gradient);
+//  * fused softmax + cross-entropy over the vocabulary (F.cross_entropy inside RegSeqCrossEntropyLoss :773):
+//    one online-softmax pass per row forward (max and sum-exp together), one pass backward.
+// Both are HBM-bound: CE reads 4*V B per token forward and reads+writes 8*V B backward (V = 47 343: 848 MB of
+// logits per 4 480-token step).
+#include "nnl_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ void emb_rowmask_fwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ W,
+                                       const float* __restrict__ rowmask, float* __restrict__ out, long n, int V, int D,
+                                       int32_t* __restrict__ err_flag) {
+  const long total = n * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int d = (int)(i - r * D);
+    const int64_t idx = x[r];
+    float v = 0.f;
+    if (idx >= 0 && idx < V) {
+      v = W[idx * D + d];
+      if (rowmask) v *= rowmask[idx];
+    } else if (err_flag && d == 0) {
+      *err_flag = 1;
+    }
+    out[i] = v;
+  }
+}
+
+__global__ void emb_rowmask_bwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ rowmask,
+                                       const float* __restrict__ dout, float* __restrict__ dW, long n, int V, int D,
+                                       long padding_idx) {
+  const long total = n * D;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D;
+    const int d = (int)(i - r * D);
+    const int64_t idx = x[r];
+    if (idx < 0 || idx >= V || idx == padding_idx) continue;
+    const float m = rowmask ? rowmask[idx] : 1.f;
+    if (m != 0.f) atomicAdd(dW + idx * D + d, dout[i] * m);
+  }
+}
+
+struct MS { float m, s; };
+__device__ __forceinline__ MS ms_merge(MS a, MS b) {
+  const float m = fmaxf(a.m, b.m);
+  MS r;
+  r.m = m;
+  r.s = (a.s == 0.f ? 0.f : a.s * expf(a.m - m)) + (b.s == 0.f ? 0.f : b.s * expf(b.m - m));
+  return r;
+}
+
+// one block per row: lse[r] = log sum exp(logits[r,:]); loss[r] = lse[r] - logits[r, target[r]]
+__global__ __launch_bounds__(kBlock) void softmax_ce_fwd_kernel(const float* __restrict__ logits,
+                                                                 const int64_t* __restrict__ target,
+                                                                 float* __restrict__ lse, float* __restrict__ loss, int V,
+                                                                 int32_t* __restrict__ err_flag) {
+  __shared__ float sm[4], ss[4];
+  const long r = blockIdx.x;
+  const float* __restrict__ row = logits + r * V;
+  MS acc = {-INFINITY, 0.f};
+  int v = threadIdx.x;
+  for (; v + 3 * kBlock < V; v += 4 * kBlock) {          // 4 independent loads in flight per lane
+    const float a = row[v], b = row[v + kBlock], c = row[v + 2 * kBlock], d = row[v + 3 * kBlock];
+    const float m = fmaxf(fmaxf(fmaxf(a, b), fmaxf(c, d)), acc.m);
+    acc.s = acc.s * expf(acc.m - m) + ((expf(a - m) + expf(b - m)) + (expf(c - m) + expf(d - m)));
+    acc.m = m;
+  }
+  for (; v < V; v += kBlock) {
+    const float a = row[v];
+    const float m = fmaxf(a, acc.m);
+    acc.s = acc.s * expf(acc.m - m) + expf(a - m);
+    acc.m = m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MS other = {__shfl_xor(acc.m, o, 64), __shfl_xor(acc.s, o, 64)};
+    acc = ms_merge(acc, other);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sm[wave] = acc.m; ss[wave] = acc.s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    MS t = {sm[0], ss[0]};
+    for (int w = 1; w < 4; ++w) t = ms_merge(t, MS{sm[w], ss[w]});
+    const float l = t.m + logf(t.s);
+    lse[r] = l;
+    const int64_t tg = target[r];
+    if (tg >= 0 && tg < V) loss[r] = l - row[tg];
+    else { loss[r] = 0.f; if (err_flag) *err_flag = 1; }
+  }
+}
+
+// out[0] = mean(loss[0..rows))  (single block, fixed order)
+__global__ void mean_kernel(const float* __restrict__ v, float* __restrict__ out, long n) {
+  __shared__ float red[kBlock];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += kBlock) a += v[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = kBlock / 2; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+
+// dlogits[r,v] = (exp(logits[r,v] - lse[r]) - [v == target[r]]) * gup / rows
+__global__ __launch_bounds__(kBlock) void softmax_ce_bwd_kernel(const float* __restrict__ logits,
+                                                                 const int64_t* __restrict__ target,
+                                                                 const float* __restrict__ lse, const float* __restrict__ gup,
+                                                                 float* __restrict__ dlogits, int V, long rows) {
+  const long r = blockIdx.x;
+  const float* __restrict__ row = logits + r * V;
+  float* __restrict__ drow = dlogits + r * V;
+  const float l = lse[r];
+  const float g = gup[0] / (float)rows;
+  const int64_t tg = target[r];
+  for (int v = threadIdx.x; v < V; v += kBlock) {
+    float p = expf(row[v] - l);
+    if (v == tg) p -= 1.f;
+    drow[v] = p * g;
+  }
+}
+
+int grid_for(long n) {
+  long b = nnl_cdiv(n, kBlock);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int nnl_embedding_rowmask_fwd(const int64_t* x, const float* W, const float* rowmask, float* out, int64_t n,
+                                         int64_t V, int64_t D, int32_t* err_flag, void* stream) {
+  NNL_CHECK_ARG(n >= 0 && V > 0 && D > 0 && D < (1 << 24), "embedding_rowmask_fwd: bad sizes");
+  if (n == 0) return NNL_OK;
+  NNL_CHECK_ARG(x && W && out, "embedding_rowmask_fwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)n * (8 + 8.0 * D));
+  hipLaunchKernelGGL(emb_rowmask_fwd_kernel, dim3(grid_for(n * D)), dim3(kBlock), 0, s, x, W, rowmask, out, (long)n, (int)V, (int)D,
+                     err_flag);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_embedding_rowmask_bwd(const int64_t* x, const float* rowmask, const float* dout, float* dW, int64_t n,
+                                         int64_t V, int64_t D, int64_t padding_idx, void* stream) {
+  NNL_CHECK_ARG(n >= 0 && V > 0 && D > 0 && D < (1 << 24), "embedding_rowmask_bwd: bad sizes");
+  NNL_CHECK_ARG(dW, "embedding_rowmask_bwd: null output");
+  hipStream_t s = (hipStream_t)stream;
+  NNL_CHECK_HIP(hipMemsetAsync(dW, 0, sizeof(float) * V * D, s));
+  if (n == 0) return NNL_OK;
+  NNL_CHECK_ARG(x && dout, "embedding_rowmask_bwd: null pointer");
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)n * (8 + 8.0 * D) + 4.0 * V * D);
+  hipLaunchKernelGGL(emb_rowmask_bwd_kernel, dim3(grid_for(n * D)), dim3(kBlock), 0, s, x, rowmask, dout, dW, (long)n, (int)V, (int)D,
+                     (long)padding_idx);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_softmax_ce_fwd(const float* logits, const int64_t* target, float* lse, float* loss_rows, float* loss_mean,
+                                  int64_t rows, int64_t V, int32_t* err_flag, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && V > 0 && V < (1L << 31) && rows < (1L << 31), "softmax_ce_fwd: bad sizes");
+  NNL_CHECK_ARG(logits && target && lse && loss_rows && loss_mean, "softmax_ce_fwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_SOFTMAX_CE, s, 4.0 * rows * V);
+  hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, logits, target, lse, loss_rows, (int)V, err_flag);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)loss_rows, loss_mean, (long)rows);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
+                                  float* dlogits, int64_t rows, int64_t V, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && V > 0 && V < (1L << 31) && rows < (1L << 31), "softmax_ce_bwd: bad sizes");
+  NNL_CHECK_ARG(logits && target && lse && grad_out && dlogits, "softmax_ce_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_SOFTMAX_CE, s, 8.0 * rows * V);
+  hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, logits, target, lse, grad_out, dlogits, (int)V,
+                     (long)rows);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}

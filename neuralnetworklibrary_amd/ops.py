@@ -379,3 +379,7 @@ class _RetinaLoss(torch.autograd.Function):
 def retina_loss(anchors, reg, clas, boxes, cats, beta=0.5, alpha=0.25, gamma=2.0):
     """[ (1-beta)*reg_loss + beta*clas_loss, reg_loss, clas_loss ] for a batch (see include/nnl.h, K6)."""
     return _RetinaLoss.apply(anchors, reg, clas, boxes, cats, beta, alpha, gamma)
+
+
+from .ops_text import (lstm_layer, embedding_rowmask, softmax_cross_entropy, cross_entropy_nd)  # noqa: E402,F401
+__all__ += ['lstm_layer', 'embedding_rowmask', 'softmax_cross_entropy', 'cross_entropy_nd']

@@ -1,0 +1,160 @@
+"""Language-model ops on the C ABI (K5 / K5b): LSTM layer, embedding with vocabulary-row dropout, fused softmax-CE.
+Imported into `ops` (use `ops.lstm_layer`, `ops.embedding_rowmask`, `ops.softmax_cross_entropy`)."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import check, lib, ptr, require_cuda, stream
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+class _LSTMRecurrence(torch.autograd.Function):
+    """The time recurrence of nn.LSTM(num_layers=1) (reference Applications/Text.py:483,513) given the input
+    projections gx [T,B,4H]: forward = nnl_lstm_fwd, backward = nnl_lstm_bwd (BPTT) + one GEMM for dW_hh."""
+
+    @staticmethod
+    def forward(ctx, gx, w_hh, h0, c0):
+        require_cuda(gx, w_hh, h0, c0)
+        gx, w_hh = _f32c(gx), _f32c(w_hh)
+        T, B, G = gx.shape
+        H = G // 4
+        h0, c0 = _f32c(h0).view(B, H), _f32c(c0).view(B, H)
+        Hp = _ceil4(H)
+        w_pad = w_hh if Hp == H else F.pad(w_hh, (0, Hp - H))
+        dev = gx.device
+        y = torch.empty(T, B, H, dtype=torch.float32, device=dev)
+        cy = torch.empty(T, B, H, dtype=torch.float32, device=dev)
+        gates = torch.empty(T, B, G, dtype=torch.float32, device=dev)
+        wsb = int(lib.nnl_lstm_workspace_bytes(B, H))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+        check(lib.nnl_lstm_fwd(ptr(gx), ptr(w_pad), ptr(h0), ptr(c0), ptr(y), ptr(cy), ptr(gates), T, B, H, ptr(ws), wsb, stream()))
+        ctx.save_for_backward(w_hh, h0, c0, y, cy, gates)
+        return y, y[-1].clone(), cy[-1].clone()
+
+    @staticmethod
+    def backward(ctx, dy, dhT, dcT):
+        w_hh, h0, c0, y, cy, gates = ctx.saved_tensors
+        T, B, H = y.shape
+        G = 4 * H
+        dev = y.device
+        dy = None if dy is None else _f32c(dy)
+        dhT = None if dhT is None else _f32c(dhT)
+        dcT = None if dcT is None else _f32c(dcT)
+        w_t = torch.empty(H, G, dtype=torch.float32, device=dev)
+        check(lib.nnl_conv2d_weight_transpose(ptr(w_hh), ptr(w_t), G, 1, 1, H, stream()))
+        dgates = torch.empty(T, B, G, dtype=torch.float32, device=dev)
+        dh0 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
+        wsb = int(lib.nnl_lstm_workspace_bytes(B, H))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+        check(lib.nnl_lstm_bwd(ptr(dy), ptr(dhT), ptr(dcT), ptr(gates), ptr(cy), ptr(c0), ptr(w_t), ptr(dgates), ptr(dh0),
+                               ptr(dc0), T, B, H, ptr(ws), wsb, stream()))
+        dw = None
+        if ctx.needs_input_grad[1]:
+            # dW_hh[4H,H] = sum_t dgates_t^T h_{t-1}: the wgrad kernel on a 1x1 "conv" over T*B "pixels"
+            Hp = _ceil4(H)
+            hprev = torch.cat([h0.view(1, B, H), y[:-1]], 0).view(T * B, H)
+            if Hp != H:
+                hprev = F.pad(hprev, (0, Hp - H))
+            g = _lib.ConvGeom(T * B, 1, 1, Hp, G, 1, 1, 1, 0, 1, 1)
+            dwp = torch.empty(G, Hp, dtype=torch.float32, device=dev)
+            wb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
+            wws = torch.empty(max(wb // 4, 1), dtype=torch.float32, device=dev)
+            check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, G)), ptr(dwp), g, ptr(wws), wb, stream()))
+            dw = dwp[:, :H] if Hp != H else dwp
+        return dgates, dw, dh0.view_as(h0), dc0.view_as(c0)
+
+
+def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
+    """One-layer LSTM over x [T,B,I] with initial state (h0, c0) [1,B,H] (or [B,H]) and the given (already
+    weight-dropped) recurrent matrix.  Returns y [T,B,H], (hT [1,B,H], cT [1,B,H]) like nn.LSTM."""
+    from . import ops
+    T, B, _ = x.shape
+    H = w_hh.shape[1]
+    gx = ops.linear(x.reshape(T * B, -1), w_ih, b_ih + b_hh).view(T, B, 4 * H)
+    y, hT, cT = _LSTMRecurrence.apply(gx, w_hh, h0.reshape(B, H), c0.reshape(B, H))
+    return y, (hT.view(1, B, H), cT.view(1, B, H))
+
+
+class _EmbeddingRowMask(torch.autograd.Function):
+    """F.embedding(x, W * mask[V,1], padding_idx) (reference Applications/Text.py:473-474) without materialising W*mask."""
+
+    @staticmethod
+    def forward(ctx, x, W, rowmask, padding_idx):
+        from .ops import index_error_flag
+        require_cuda(x, W, rowmask)
+        xi = x.contiguous().long()
+        W = _f32c(W)
+        rm = None if rowmask is None else _f32c(rowmask).view(-1)
+        V, D = W.shape
+        out = torch.empty(xi.numel(), D, dtype=torch.float32, device=W.device)
+        check(lib.nnl_embedding_rowmask_fwd(ptr(xi), ptr(W), ptr(rm), ptr(out), xi.numel(), V, D,
+                                            ptr(index_error_flag(W.device)), stream()))
+        ctx.save_for_backward(xi, rm)
+        ctx.meta = (V, D, -1 if padding_idx is None else int(padding_idx))
+        return out.view(*x.shape, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xi, rm = ctx.saved_tensors
+        V, D, pad = ctx.meta
+        dout = _f32c(dout)
+        dW = torch.empty(V, D, dtype=torch.float32, device=dout.device)
+        check(lib.nnl_embedding_rowmask_bwd(ptr(xi), ptr(rm), ptr(dout), ptr(dW), xi.numel(), V, D, pad, stream()))
+        return None, dW, None, None
+
+
+def embedding_rowmask(x, W, rowmask=None, padding_idx=None):
+    return _EmbeddingRowMask.apply(x, W, rowmask, padding_idx)
+
+
+class _SoftmaxCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        from .ops import index_error_flag
+        require_cuda(logits, target)
+        logits = _f32c(logits)
+        target = target.contiguous().long()
+        rows, V = logits.shape
+        dev = logits.device
+        lse = torch.empty(rows, dtype=torch.float32, device=dev)
+        loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        check(lib.nnl_softmax_ce_fwd(ptr(logits), ptr(target), ptr(lse), ptr(loss_rows), ptr(loss), rows, V,
+                                     ptr(index_error_flag(dev)), stream()))
+        ctx.save_for_backward(logits, target, lse)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, lse = ctx.saved_tensors
+        g = _f32c(dloss).view(1)
+        dlogits = torch.empty_like(logits)
+        check(lib.nnl_softmax_ce_bwd(ptr(logits), ptr(target), ptr(lse), ptr(g), ptr(dlogits), logits.shape[0], logits.shape[1],
+                                     stream()))
+        return dlogits, None
+
+
+def softmax_cross_entropy(logits, target):
+    """mean_r( logsumexp(logits[r]) - logits[r, target[r]] ) for logits [rows, V], target [rows]."""
+    return _SoftmaxCE.apply(logits, target)
+
+
+def cross_entropy_nd(preds, target):
+    """F.cross_entropy(preds, target) for class-dim-1 inputs: [N,C] with target [N], or [N,C,d1..] with [N,d1..]."""
+    if preds.dim() == 2:
+        return softmax_cross_entropy(preds, target)
+    C = preds.shape[1]
+    if preds.dim() == 3 and preds.permute(2, 0, 1).is_contiguous():
+        # the language-model decoder returns lin(x).permute(1,2,0): a [bs,V,seq] VIEW of a contiguous [seq,bs,V]
+        # buffer (Text.py:572) — use that buffer as is (the mean does not depend on the row order)
+        return softmax_cross_entropy(preds.permute(2, 0, 1).reshape(-1, C), target.transpose(0, 1).reshape(-1))
+    perm = [0] + list(range(2, preds.dim())) + [1]
+    return softmax_cross_entropy(preds.permute(*perm).reshape(-1, C), target.reshape(-1))

@@ -287,7 +287,124 @@ def g8_detection():
     save('g8_detection', **out)
 
 
-GROUPS = {'g1': g1_collab, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
+class _FixedDrop(torch.nn.Module):
+    "stands in for an nn.Dropout inside a reference module: returns pre-drawn masks in call order"
+    def __init__(self, masks):
+        super().__init__()
+        self.masks, self.i = masks, 0
+    def forward(self, t):
+        m = self.masks[self.i % len(self.masks)]
+        self.i += 1
+        assert tuple(m.shape) == tuple(t.shape), (m.shape, t.shape)
+        return t * m
+
+
+def _mask(shape, p, tag):
+    keep = (np.random.RandomState(tag).rand(*shape) >= p).astype(np.float32)
+    return torch.from_numpy(keep / (1 - p))
+
+
+def g7_text():
+    """G7: WeightDropLSTM1(8,12) with an injected weight mask (y, hT, cT, all grads); LSTM_Encoder(V=50, emb 8, hid 12,
+    3 layers) in training mode with every dropout mask injected, two consecutive batches (hidden-state carry);
+    full-size LanguageModelNet (400/1150/3, V=60, dropout 0): RegSeqCrossEntropyLoss(2,1) forward/backward and two
+    Learner.train1minibatch steps (Adam betas (0.8,0.99), lr [1e-3,2e-3], wd 1e-6, clip 0.4)."""
+    TX = R['Applications.Text']
+    out = {}
+    # (a) one weight-dropped layer
+    T, B, I, H = 6, 4, 8, 12
+    m = TX.WeightDropLSTM1(I, H, 0.5)
+    m.clear_non_raw()
+    synth.fill_module_(m, seed=7)
+    wmask = _mask((4 * H, H), 0.5, 31)
+    m.weight_drop = _FixedDrop([wmask])
+    x = synth.synth_input((T, B, I), 41).requires_grad_(True)
+    h0, c0 = synth.synth_input((1, B, H), 42, 0.5), synth.synth_input((1, B, H), 43, 0.5)
+    y, (hT, cT) = m(x, (h0, c0))
+    dy = synth.synth_input((T, B, H), 44)
+    (y * dy).sum().backward()
+    out.update({'a.wmask': A(wmask), 'a.y': A(y), 'a.hT': A(hT), 'a.cT': A(cT), 'a.dx': A(x.grad)})
+    for n, p in m.named_parameters():
+        out['a.grad.' + n] = A(p.grad)
+    out['a.param_names'] = np.array([n for n, _ in m.named_parameters()])
+    # (b) encoder, two consecutive batches, all masks injected
+    V, E, Hh, bs, seq = 50, 8, 12, 4, 5
+    enc = TX.LSTM_Encoder(V, E, Hh, 3, 1, [0.3, 0.3, 0.4, 0.3], bs)
+    for l in enc.lstms:
+        l.clear_non_raw()
+    synth.fill_module_(enc, seed=8)
+    sizes = [E, Hh, Hh, E]
+    masks = {'emb_rows': _mask((V, 1), 0.3, 51), 'emb_locked': _mask((1, bs, E), 0.3, 52),
+             'weights': [_mask((4 * sizes[i + 1], sizes[i + 1]), 0.4, 53 + i) for i in range(3)],
+             'hidden': [_mask((1, bs, sizes[i + 1]), 0.3, 56 + i) for i in range(3)]}
+    enc.word_embed.drop1 = _FixedDrop([masks['emb_rows']])
+    enc.word_embed.drop2.drop = _FixedDrop([masks['emb_locked']])
+    for i, l in enumerate(enc.lstms):
+        l.weight_drop = _FixedDrop([masks['weights'][i]])
+    enc.hidden_drop.drop = _FixedDrop(masks['hidden'])
+    enc.train()
+    rs = np.random.RandomState(61)
+    for b in range(2):
+        xb = torch.from_numpy(rs.randint(0, V, (bs, seq)).astype(np.int64))
+        ob = enc(xb)
+        out['b.x%d' % b], out['b.out%d' % b] = A(xb), A(ob)
+    dyb = synth.synth_input(tuple(ob.shape), 62)
+    (ob * dyb).sum().backward()
+    for n, p in enc.named_parameters():
+        out['b.grad.' + n] = A(p.grad)
+    for k in ['emb_rows', 'emb_locked']:
+        out['b.mask.' + k] = A(masks[k])
+    for i in range(3):
+        out['b.mask.weights%d' % i], out['b.mask.hidden%d' % i] = A(masks['weights'][i]), A(masks['hidden'][i])
+    out['b.h_final0'], out['b.c_final2'] = A(enc.h[0]), A(enc.c[2])
+    # (c) full-size language model, dropout 0
+    class D:
+        pass
+    Vc, bs, seq = 60, 4, 7
+    d = D(); d.stoi = {('tok%d' % i): i for i in range(Vc)}; d.stoi['_pad_'] = 1; d.bs = bs; d.target_type = 'lang_model'
+    del d.stoi['tok1']
+    net = TX.LanguageModelNet(d, enc_drops=[0., 0., 0., 0.], dec_drop=0.)
+    net.clear_non_raw()
+    synth.fill_module_(net, seed=9)
+    with torch.no_grad():
+        net.enc.word_embed.embed.weight.mul_(0.3)
+    rs = np.random.RandomState(71)
+    stream_ = rs.randint(0, Vc, (bs, 2 * seq + 1)).astype(np.int64)
+    batches = [(torch.from_numpy(stream_[:, i * seq:(i + 1) * seq].copy()), torch.from_numpy(stream_[:, i * seq + 1:(i + 1) * seq + 1].copy()))
+               for i in range(2)]
+    for i, (xb, yb) in enumerate(batches):
+        out['c.x%d' % i], out['c.y%d' % i] = A(xb), A(yb)
+    lf = TX.RegSeqCrossEntropyLoss(2.0, 1.0)
+    net.train()
+    outp = net(batches[0][0])
+    loss = lf(outp, batches[0][1])
+    loss.backward()
+    out['c.loss'], out['c.ce'] = A(loss), A(lf.cross_entropy)
+    out['c.preds_slice'] = A(outp[0])[:, :, :2].copy()
+    out['c.param_names'] = np.array([n for n, _ in net.named_parameters()])
+    out['c.grad_norms'] = np.array([p.grad.norm().item() for _, p in net.named_parameters()], dtype=np.float64)
+    sd = dict(net.named_parameters())
+    out['c.grad.emb'] = A(sd['enc.word_embed.embed.weight'].grad)
+    out['c.grad.whh0_slice'] = A(sd['enc.lstms.0.lstm.weight_hh_l0_raw'].grad)[:64, :64].copy()
+    out['c.grad.bias2'] = A(sd['enc.lstms.2.lstm.bias_ih_l0'].grad)
+    # two real Learner steps on a fresh net (state carried from batch 0 to batch 1)
+    net = TX.LanguageModelNet(d, enc_drops=[0., 0., 0., 0.], dec_drop=0.)
+    net.clear_non_raw()
+    synth.fill_module_(net, seed=9)
+    with torch.no_grad():
+        net.enc.word_embed.embed.weight.mul_(0.3)
+    d.train_dl, d.val_dl = batches, batches
+    learner = Learner('/tmp/nnl_golden_g7', d, net, optimizer='Adam', loss_func=TX.RegSeqCrossEntropyLoss(2.0, 1.0))
+    learner.init_optimizer(wd=1e-6, clip=0.4)
+    net.train()
+    out['c.step_losses'] = np.array([learner.train1minibatch(xb, yb, [1e-3, 2e-3], betas_batch=(0.8, 0.99)) for xb, yb in batches],
+                                    dtype=np.float64)
+    out['c.after.abs_sums'] = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+    out['c.after.emb'] = A(net.enc.word_embed.embed.weight)
+    save('g7_text', **out)
+
+
+GROUPS = {'g1': g1_collab, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)

@@ -1,0 +1,207 @@
+"""Language-model path (K5 / K5b): oracle pinned to the reference golden G7 on CPU; HIP product vs golden / oracle on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import T, assert_close, load_golden
+from oracle import reference_math as RM
+from oracle import reference_text as RT
+from oracle import synth
+
+DEV = 'cuda'
+
+
+def lm_group_of(name):
+    "layer groups of LanguageModelNet: [enc.lstms, head=dec(tied embedding)] (Text.py:642)"
+    return 0 if '.lstms.' in name else 1
+
+
+def b_masks(g, dev='cpu'):
+    return {'emb_rows': T(g['b.mask.emb_rows'], dev), 'emb_locked': T(g['b.mask.emb_locked'], dev),
+            'weights': [T(g['b.mask.weights%d' % i], dev) for i in range(3)],
+            'hidden': [T(g['b.mask.hidden%d' % i], dev) for i in range(3)]}
+
+
+def check_layer(mod, g, dev, call, rtol):
+    synth.fill_module_(mod, seed=7)
+    mod = mod.to(dev)
+    x = synth.synth_input((6, 4, 8), 41).to(dev).requires_grad_(True)
+    h0, c0 = synth.synth_input((1, 4, 12), 42, 0.5).to(dev), synth.synth_input((1, 4, 12), 43, 0.5).to(dev)
+    y, (hT, cT) = call(mod, x, (h0, c0), T(g['a.wmask'], dev))
+    assert_close(y, g['a.y'], rtol, 1e-6, 'y'); assert_close(hT, g['a.hT'], rtol, 1e-6, 'hT'); assert_close(cT, g['a.cT'], rtol, 1e-6, 'cT')
+    (y * synth.synth_input((6, 4, 12), 44).to(dev)).sum().backward()
+    assert_close(x.grad, g['a.dx'], rtol * 10, 1e-6, 'dx')
+    assert [n for n, _ in mod.named_parameters()] == [str(s) for s in g['a.param_names']]
+    for n, p in mod.named_parameters():
+        assert_close(p.grad, g['a.grad.' + n], rtol * 10, 1e-5, 'grad ' + n)
+
+
+def check_encoder(enc, g, dev, call, rtol):
+    synth.fill_module_(enc, seed=8)
+    enc = enc.to(dev)
+    enc.train()
+    masks = b_masks(g, dev)
+    for b in range(2):
+        out = call(enc, T(g['b.x%d' % b], dev), masks)
+        assert_close(out, g['b.out%d' % b], rtol, 1e-6, 'out%d' % b)
+    (out * synth.synth_input(tuple(out.shape), 62).to(dev)).sum().backward()
+    for n, p in enc.named_parameters():
+        assert_close(p.grad, g['b.grad.' + n], rtol * 10, 1e-5, 'grad ' + n)
+    assert_close(enc.h[0], g['b.h_final0'], rtol, 1e-6, 'carried h'); assert_close(enc.c[2], g['b.c_final2'], rtol, 1e-6, 'carried c')
+
+
+def test_g7_layer_oracle():
+    g = load_golden('g7_text')
+    check_layer(RT.WeightDropLSTM1(8, 12), g, 'cpu', lambda m, x, hc, wm: m(x, hc, wm), 1e-5)
+
+
+def test_g7_encoder_oracle():
+    g = load_golden('g7_text')
+    check_encoder(RT.LSTM_Encoder(50, 8, 12, 3, 1, 4), g, 'cpu', lambda e, x, m: e(x, m), 1e-5)
+
+
+def _lm_setup(net, scale_emb=True):
+    synth.fill_module_(net, seed=9)
+    with torch.no_grad():
+        net.enc.word_embed.embed.weight.mul_(0.3)
+    return net
+
+
+def check_lm_forward_backward(net, lossf, g, dev, rtol):
+    net.train()
+    x, y = T(g['c.x0'], dev), T(g['c.y0'], dev)
+    out = net(x)
+    loss, ce = lossf(out, y)
+    assert_close(loss, g['c.loss'], rtol, 1e-6, 'loss'); assert_close(ce, g['c.ce'], rtol, 1e-6, 'ce')
+    assert_close(out[0][:, :, :2], g['c.preds_slice'], rtol * 10, 1e-5, 'preds')
+    loss.backward()
+    assert [n for n, _ in net.named_parameters()] == [str(s) for s in g['c.param_names']]
+    norms = np.array([p.grad.norm().item() for _, p in net.named_parameters()])
+    assert_close(norms, g['c.grad_norms'], 1e-3, 1e-8, 'grad norms')
+    sd = dict(net.named_parameters())
+    assert_close(sd['enc.word_embed.embed.weight'].grad, g['c.grad.emb'], 1e-3, 1e-6, 'tied embedding grad')
+    assert_close(sd['enc.lstms.0.lstm.weight_hh_l0_raw'].grad[:64, :64], g['c.grad.whh0_slice'], 1e-3, 1e-7, 'w_hh grad')
+    assert_close(sd['enc.lstms.2.lstm.bias_ih_l0'].grad, g['c.grad.bias2'], 1e-3, 1e-7, 'bias grad')
+
+
+def test_g7_language_model_oracle():
+    g = load_golden('g7_text')
+    net = _lm_setup(RT.LanguageModelNet(60, 1, 4))
+    check_lm_forward_backward(net, lambda o, y: RT.reg_seq_cross_entropy(o, y, 2.0, 1.0), g, 'cpu', 1e-5)
+    # two restated Learner steps: Adam betas (.8,.99), lr [1e-3, 2e-3] per layer group, wd 1e-6, clip 0.4
+    net = _lm_setup(RT.LanguageModelNet(60, 1, 4)).train()
+    names = [n for n, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    # the reference Optimizer orders torch param groups [reg_0, reg_1, bn_0, bn_1]; the tied embedding sits in BOTH layer
+    # groups' module lists only once as a Parameter of group 1's decoder AND group... it is a parameter of enc.word_embed,
+    # which is in neither layer group: it is reached through dec.lin.weight (group 1)
+    lrs = [[1e-3, 2e-3][lm_group_of(n)] for n in names]
+    state = RM.OptimState(params)
+    losses = []
+    for i in range(2):
+        for p in params:
+            p.grad = None
+        loss, _ = RT.reg_seq_cross_entropy(net(T(g['c.x%d' % i])), T(g['c.y%d' % i]), 2.0, 1.0)
+        loss.backward()
+        losses.append(loss.item())
+        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [1e-6] * len(params), 'adam', betas=(0.8, 0.99), clip=0.4)
+    assert_close(np.array(losses), g['c.step_losses'], 1e-5, 1e-7, 'step losses')
+    assert_close(np.array([p.double().abs().sum().item() for p in params]), g['c.after.abs_sums'], 1e-5, 1e-8, 'abs sums')
+    assert_close(net.enc.word_embed.embed.weight, g['c.after.emb'], 1e-4, 2e-5, 'embedding after 2 steps')   # Adam: lr*m/(sqrt(v)+eps) amplifies 1e-8 grad noise on near-zero-grad rows
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_g7_layer_hip():
+    from neuralnetworklibrary_amd.Applications.Text import WeightDropLSTM1
+    g = load_golden('g7_text')
+    check_layer(WeightDropLSTM1(8, 12, 0.5), g, DEV, lambda m, x, hc, wm: m(x, hc, wm), 1e-4)
+
+
+@pytest.mark.gpu
+def test_g7_encoder_hip():
+    from neuralnetworklibrary_amd.Applications.Text import LSTM_Encoder
+    g = load_golden('g7_text')
+
+    def call(enc, x, masks):
+        enc.fixed_masks = masks
+        return enc(x)
+    check_encoder(LSTM_Encoder(50, 8, 12, 3, 1, [0.3, 0.3, 0.4, 0.3], 4), g, DEV, call, 1e-4)
+
+
+def _product_lm():
+    from neuralnetworklibrary_amd.Applications.Text import LanguageModelNet, _Vocab
+    stoi = {('tok%d' % i): i for i in range(60)}
+    stoi['_pad_'] = 1
+    del stoi['tok1']
+    d = _Vocab(stoi, 4)
+    d.target_type = 'lang_model'
+    return _lm_setup(LanguageModelNet(d, enc_drops=[0., 0., 0., 0.], dec_drop=0.)).to(DEV), d
+
+
+@pytest.mark.gpu
+def test_g7_language_model_hip():
+    from neuralnetworklibrary_amd.Applications.Text import RegSeqCrossEntropyLoss
+    g = load_golden('g7_text')
+    net, _ = _product_lm()
+    lf = RegSeqCrossEntropyLoss(2.0, 1.0)
+    check_lm_forward_backward(net, lambda o, y: (lf(o, y), lf.cross_entropy), g, DEV, 1e-4)
+
+
+@pytest.mark.gpu
+def test_g7_language_model_hip_learner_steps():
+    from neuralnetworklibrary_amd.Applications.Text import RegSeqCrossEntropyLoss
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    g = load_golden('g7_text')
+    net, d = _product_lm()
+    batches = [(T(g['c.x%d' % i], DEV), T(g['c.y%d' % i], DEV)) for i in range(2)]
+    d.train_dl, d.val_dl = batches, batches
+    learner = Learner('/tmp/nnl_test_g7', d, net, optimizer='Adam', loss_func=RegSeqCrossEntropyLoss(2.0, 1.0))
+    learner.init_optimizer(wd=1e-6, clip=0.4)
+    net.train()
+    losses = [learner.train1minibatch(x, y, [1e-3, 2e-3], betas_batch=(0.8, 0.99)) for x, y in batches]
+    assert_close(np.array(losses), g['c.step_losses'], 1e-4, 1e-6, 'step losses')
+    assert_close(np.array([p.double().abs().sum().item() for p in net.parameters()]), g['c.after.abs_sums'], 1e-4, 1e-7, 'abs sums')
+    assert_close(net.enc.word_embed.embed.weight, g['c.after.emb'], 1e-3, 1e-4, 'embedding after 2 steps')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,V', [(7, 10), (64, 47343), (33, 1001)])
+def test_softmax_ce_vs_torch(rows, V):
+    from neuralnetworklibrary_amd import ops
+    gen = torch.Generator().manual_seed(rows + V)
+    logits = torch.randn(rows, V, generator=gen) * 3
+    logits[0, :min(V, 5)] += 30                      # a dominant class: exercises the online-max rescale
+    target = torch.randint(0, V, (rows,), generator=gen)
+    lc = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lc, target)
+    ref.backward()
+    lg = logits.to(DEV).requires_grad_(True)
+    out = ops.softmax_cross_entropy(lg, target.to(DEV))
+    out.backward()
+    assert_close(out, ref, 1e-5, 1e-6, 'loss')
+    assert_close(lg.grad, lc.grad, 1e-4, 1e-9, 'dlogits')
+    ops.raise_if_index_error()
+
+
+@pytest.mark.gpu
+def test_embedding_rowmask_bit_exact_and_grad():
+    from neuralnetworklibrary_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    V, D = 977, 400
+    W = torch.randn(V, D, generator=gen)
+    x = torch.randint(0, V, (70, 64), generator=gen)
+    out = ops.embedding_rowmask(x.to(DEV), W.to(DEV), None, 1)
+    assert torch.equal(out.cpu(), W[x])                                   # index gather is bit exact
+    mask = (torch.rand(V, 1, generator=gen) > 0.3).float() / 0.7
+    Wc = W.clone().requires_grad_(True)
+    ref = torch.nn.functional.embedding(x, Wc * mask, 1)
+    dy = torch.randn(ref.shape, generator=gen)
+    ref.backward(dy)
+    Wg = W.to(DEV).requires_grad_(True)
+    o = ops.embedding_rowmask(x.to(DEV), Wg, mask.to(DEV), 1)
+    o.backward(dy.to(DEV))
+    assert_close(o, ref, 1e-6, 1e-7, 'out')
+    assert_close(Wg.grad, Wc.grad, 1e-4, 1e-5, 'dW')
+    assert float(Wg.grad[1].abs().sum()) == 0.0                            # padding row gets no gradient
