@@ -105,7 +105,7 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     per_gpu_bs = args.bs if args.scaling == 'weak' else max(args.bs // world, 1)
-    learner, data = build_learner(device, per_gpu_bs, args.sz, 1234 + 1)
+    learner, data = build_learner(device, per_gpu_bs, args.sz, 1234 + 1 + 1000 * rank)
     if world > 1:
         learner.distribute()
     learner.model.train()

@@ -99,7 +99,7 @@ class Learner(object):
         self.grad_sync = None
 
     # ---- data parallelism (new) -----------------------------------------------------
-    def distribute(self, bucket_mb=25.0, sync_bn=True):
+    def distribute(self, bucket_mb=25.0, sync_bn=False):
         """Make this learner one rank of a synchronous data-parallel job (one process per GPU)."""
         from .. import dist as nnl_dist
         self.grad_sync = nnl_dist.GradSync(self.model, bucket_mb=bucket_mb)

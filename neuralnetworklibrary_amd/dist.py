@@ -1,0 +1,172 @@
+"""Synchronous data parallelism for Learner.fit(): one process per GPU, gradients all-reduced over RCCL/xGMI.
+
+The reference is single-GPU ("if a machine has multiple GPUs only 1 of them will be utilized", README.md:11-12); this
+module is the MI355X-native addition.  Design for the node's topology (8 GPUs, point-to-point xGMI,
+7 links/GPU): a ring all-reduce is per-link bound, so gradients are packed into a few LARGE flat buckets (default
+25 MB, ResNet-34's 87 MB -> 4 collectives) that RCCL can spread over all links, and each bucket's all-reduce is launched
+from a post-accumulate-grad hook as soon as its last gradient is produced, i.e. in reverse layer order while the rest
+of backward is still running on the compute stream (RCCL runs on its own stream).  `finish()` (called by
+Optimizer.step) waits for the collectives, and `param.grad` becomes a view of the averaged flat bucket (no copy back).
+
+Numerics: every rank computes the mean loss of its local shard; averaging the gradients over ranks equals the gradient
+of the global-batch mean when shards have equal size.  BatchNorm uses per-replica batch statistics (standard DDP
+semantics; at the benchmark's 64 images per GPU that is exactly the reference's batch-statistics population).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+__all__ = ['init_from_env', 'GradSync', 'ShardedBatches', 'enable_sync_bn', 'world_size', 'rank']
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run sets
+    them).  backend: 'nccl' (= RCCL on ROCm) when a GPU is visible, else 'gloo'.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rk = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        use_gpu = torch.cuda.is_available()
+        backend = backend or ('nccl' if use_gpu else 'gloo')
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if use_gpu:
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rk, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rk, world_size=world)
+    return rk, world, local
+
+
+class _Bucket:
+    def __init__(self, params, device):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.views, o = [], 0
+        for p in params:
+            self.views.append(self.flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        self.pending = len(params)
+        self.ready = [False] * len(params)
+        self.handle = None
+
+
+class GradSync:
+    """Bucketed, backward-overlapped gradient all-reduce (mean over ranks) for `model`'s trainable parameters."""
+
+    def __init__(self, model, bucket_mb=25.0, group=None):
+        self.model, self.bucket_bytes, self.group = model, int(bucket_mb * 2 ** 20), group
+        self._hooks = []
+        self.rebuild()
+
+    def rebuild(self):
+        """(Re)build buckets and hooks — call after freezing / unfreezing parameters."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self.buckets, self._where = [], [], {}
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        seen, uniq = set(), []
+        for p in params:
+            if id(p) not in seen:                      # tied weights (LM decoder/embedding) appear once
+                seen.add(id(p)); uniq.append(p)
+        cur, cur_bytes = [], 0
+        for p in reversed(uniq):                       # reverse registration order ~ order gradients become ready
+            cur.append(p); cur_bytes += p.numel() * 4
+            if cur_bytes >= self.bucket_bytes:
+                self.buckets.append(_Bucket(cur, p.device)); cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(_Bucket(cur, cur[0].device))
+        for bi, b in enumerate(self.buckets):
+            for pi, p in enumerate(b.params):
+                self._where[id(p)] = (bi, pi)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._active = False
+
+    def begin(self):
+        "Arm the hooks for one backward pass (Learner.train1minibatch calls this before the forward)."
+        for b in self.buckets:
+            b.pending, b.ready, b.handle = len(b.params), [False] * len(b.params), None
+        self._active = True
+
+    def _launch(self, b):
+        if world_size() > 1:
+            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._active:
+            return
+        bi, pi = self._where[id(p)]
+        b = self.buckets[bi]
+        if b.ready[pi]:
+            return
+        b.views[pi].copy_(p.grad)
+        b.ready[pi] = True
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def finish(self):
+        "Wait for every bucket, average, and point param.grad at the averaged bucket views."
+        if not self._active:
+            return
+        self._active = False
+        w = world_size()
+        for b in self.buckets:
+            if b.pending > 0:                          # parameters that received no gradient this step
+                if b.pending == len(b.params) and all(p.grad is None for p in b.params):
+                    continue
+                for pi, p in enumerate(b.params):
+                    if not b.ready[pi]:
+                        b.views[pi].zero_() if p.grad is None else b.views[pi].copy_(p.grad)
+                self._launch(b)
+        for b in self.buckets:
+            if b.handle is not None:
+                b.handle.wait()
+                b.handle = None
+            elif b.pending == len(b.params):
+                continue
+            if w > 1:
+                b.flat.mul_(1.0 / w)
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+
+
+class ShardedBatches:
+    """Wrap an iterable of (x, y) GLOBAL minibatches: each rank gets its contiguous slice along dim 0 (samples; for the
+    language model dim 0 is the stream dimension, so a rank keeps the same streams — and their carried hidden state —
+    from batch to batch, Text.py:254-263).  len() is unchanged, so schedules are identical on every rank."""
+
+    def __init__(self, batches, rank_=None, world=None):
+        self.batches = batches
+        self.rank = rank() if rank_ is None else rank_
+        self.world = world_size() if world is None else world
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _cut(self, t):
+        if isinstance(t, (list, tuple)):
+            return [self._cut(v) for v in t]
+        n = t.shape[0]
+        per = (n + self.world - 1) // self.world
+        return t[self.rank * per:min((self.rank + 1) * per, n)]
+
+    def __iter__(self):
+        for x, y in self.batches:
+            yield self._cut(x), self._cut(y)
+
+
+def enable_sync_bn(model):
+    """Cross-replica BatchNorm statistics are not implemented yet (SURVEY.md §8e lists them as a parity-only extra):
+    replicas use local batch statistics.  Kept as an explicit no-op so callers can opt in once it exists."""
+    return model

@@ -29,7 +29,7 @@ def install():
     _stub('cv2')
     sk = _stub('skimage'); sk.io = _stub('skimage.io'); sk.transform = _stub('skimage.transform')
     _stub('GPUtil')
-    ip = _stub('IPython'); ip.display = _stub('IPython.display', clear_output=lambda *a, **k: None)
+    ip = _stub('IPython', get_ipython=lambda: None, version_info=(0, 0)); ip.display = _stub('IPython.display', clear_output=lambda *a, **k: None)
 
     class _ResNet(nn.Module):
         pass

@@ -404,7 +404,82 @@ def g7_text():
     save('g7_text', **out)
 
 
-GROUPS = {'g1': g1_collab, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
+def g9_host_logic():
+    """G9+G10: Optimizer.step (wd / bn_wd / clip, SGD-momentum and Adam) on a 2-layer-group toy model; Learner.get_sched
+    for its four types (scalar and vector); fit_one_cycle lr / mom / betas schedules; 2-epoch Learner.fit,
+    fit_cycles and find_lr loss curves on a toy regression problem (reference Learner driving a plain torch model)."""
+    Core = R['General.Core']
+    out = {}
+
+    def toy():
+        torch.manual_seed(0)
+        g1 = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Tanh())
+        g2 = torch.nn.Sequential(torch.nn.Linear(7, 1), torch.nn.Flatten(0))
+        net = torch.nn.Sequential(g1, g2)
+        synth.fill_module_(net, seed=11)
+        net.layer_groups = [g1, g2]
+        net.param_groups = Core.separate_bn_layers(net.layer_groups)
+        return net
+
+    rs = np.random.RandomState(3)
+    X = torch.from_numpy(rs.standard_normal((40, 5)).astype(np.float32))
+    Y = torch.from_numpy(rs.standard_normal(40).astype(np.float32))
+    out['X'], out['Y'] = A(X), A(Y)
+    batches = [(X[i:i + 8], Y[i:i + 8]) for i in range(0, 36, 8)]          # 4 full batches + one of 4 (ragged)
+    # --- Optimizer.step variants
+    for tag, opt, kw in [('sgd', 'SGD_Mom', dict(wd=[1e-2, 3e-2], bn_wd=True, clip=0.5)),
+                         ('adam', 'Adam', dict(wd=1e-2, bn_wd=False, clip=None))]:
+        net = toy()
+        LN = R['General.Learner']
+        o = Optimizer(LN.opt_dict[opt], net)
+        o.set_params([1e-1, 3e-1], **kw)
+        for step in range(3):
+            o.opt.zero_grad()
+            ((net(X[:8]) - Y[:8]) ** 2).mean().backward()
+            o.step()
+        for n, p in net.named_parameters():
+            out['opt.%s.%s' % (tag, n)] = A(p)
+    # --- schedules
+    Lr = Learner.get_sched
+    for st in ['linear', 'cos', 'exp', 'poly']:
+        out['sched.%s.scalar' % st] = np.array(Lr(st, 7, 1e-3, 1e-1), dtype=np.float64)
+        out['sched.%s.vector' % st] = np.array(Lr(st, 5, [1e-3, 2e-3], [1e-1, 4e-1]), dtype=np.float64)
+    data = FakeData(batches, batches[:2], 8, 'cont')
+    for opt in ['SGD_Mom', 'Adam']:
+        learner = Learner('/tmp/nnl_golden_g9', data, toy(), optimizer=opt)
+        captured = {}
+        learner.train_gen_sched = lambda lr, mom, betas, *a, **k: captured.update(lr=lr, mom=mom, betas=betas)
+        learner.fit_one_cycle([1e-2, 3e-2], 2, wd=1e-3)
+        out['onecycle.%s.lr' % opt] = np.array(captured['lr'], dtype=np.float64)
+        if captured['mom'] is not None:
+            out['onecycle.%s.mom' % opt] = np.array(captured['mom'], dtype=np.float64)
+        if captured['betas'] is not None:
+            out['onecycle.%s.betas' % opt] = np.array(captured['betas'], dtype=np.float64)
+    # --- full fit loops (loss per minibatch, lr bookkeeping, final weights)
+    learner = Learner('/tmp/nnl_golden_g9', data, toy(), optimizer='SGD_Mom')
+    learner.fit([3e-2, 1e-1], 2, wd=1e-3, clip=1.0, momentum=0.8)
+    out['fit.loss_sched'] = np.array(learner.loss_sched, dtype=np.float64)
+    out['fit.moving_avg'] = np.array([learner.moving_avg_loss])
+    out['fit.w'] = np.concatenate([A(p).reshape(-1) for p in learner.model.parameters()])
+    learner = Learner('/tmp/nnl_golden_g9', data, toy(), optimizer='Adam')
+    learner.fit_cycles(3e-2, 1e-3, 2, cycle_type='cos', base_length=1, cycle_mult=2, wd=1e-3, betas=(0.8, 0.99))
+    out['cycles.loss_sched'] = np.array(learner.loss_sched, dtype=np.float64)
+    out['cycles.lr_sched'] = np.array(learner.lr_sched, dtype=np.float64)
+    out['cycles.w'] = np.concatenate([A(p).reshape(-1) for p in learner.model.parameters()])
+    import matplotlib
+    matplotlib.use('Agg')
+    learner = Learner('/tmp/nnl_golden_g9', data, toy(), optimizer='SGD_Mom')
+    w_before = np.concatenate([A(p).reshape(-1) for p in learner.model.parameters()])
+    learner.find_lr(lr_min=1e-4, lr_max=1.0, length=8, break_fac=None)
+    out['findlr.loss_sched'] = np.array(learner.loss_sched, dtype=np.float64)
+    out['findlr.lr_sched'] = np.array(learner.lr_sched, dtype=np.float64)
+    out['findlr.restored'] = np.array([np.abs(np.concatenate([A(p).reshape(-1) for p in learner.model.parameters()]) - w_before).max()])
+    ev = learner.evaluate('val')
+    out['evaluate.val'] = np.array(ev[0:1], dtype=np.float64)
+    save('g9_host_logic', **out)
+
+
+GROUPS = {'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)

@@ -1,0 +1,131 @@
+"""Data-parallel logic on CPU with the gloo backend, world_size 2 (the RCCL path is the same code with backend 'nccl'):
+bucketed gradient averaging == single-process gradients on the concatenated batch; a 2-rank Learner.fit reproduces the
+1-rank run on the global batches (loss curve and final weights); ragged last batch lr scaling uses the global size."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _model(seed=0):
+    from neuralnetworklibrary_amd.General.Core import make_model_basic
+    torch.manual_seed(seed)
+    net = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 1), nn.Flatten(0))
+    return make_model_basic(net)
+
+
+def _batches(n_batches=5, bs=8, last=6):
+    g = torch.Generator().manual_seed(3)
+    out = []
+    for i in range(n_batches):
+        b = last if i == n_batches - 1 else bs
+        out.append((torch.randn(b, 6, generator=g), torch.randn(b, generator=g)))
+    return out
+
+
+class _Data:
+    target_type = 'cont'
+
+    def __init__(self, batches, bs):
+        self.train_dl, self.val_dl, self.bs = batches, batches, bs
+
+
+def _fit(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device('cpu')
+    torch.set_num_threads(1)
+    Learner.verbose = False
+    if world > 1:
+        nd.init_from_env('gloo')
+    batches = _batches()
+    shard = nd.ShardedBatches(batches, rank, world)
+    data = _Data(shard, 8 // world)
+    net = _model()
+    learner = Learner('/tmp/nnl_dist_test_%d_%d' % (world, rank), data, net, optimizer='Adam')
+    if world > 1:
+        learner.distribute(bucket_mb=0.0005)          # tiny buckets: several collectives per step
+        assert len(learner.grad_sync.buckets) > 1
+    learner.fit(1e-2, 2, wd=1e-3, clip=1.0)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    if rank == 0:
+        q.put((learner.loss_sched, flat.numpy()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_two_rank_fit_matches_single_rank():
+    losses1, w1 = _run(1)
+    losses2, w2 = _run(2)
+    # rank 0's logged loss is the mean over ITS shard; the averaged gradients (hence the weights) must match exactly
+    np.testing.assert_allclose(w2, w1, rtol=2e-5, atol=2e-6)
+    assert len(losses1) == len(losses2) == 10
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    torch.set_num_threads(1)
+    nd.init_from_env('gloo')
+    net = _model(1)
+    net[4].weight.requires_grad_(False)               # a frozen parameter is simply not synchronised
+    sync = nd.GradSync(net, bucket_mb=0.0003)
+    x, y = _batches(1, 8, 8)[0]
+    xs, ys = nd.ShardedBatches([(x, y)], rank, world).__iter__().__next__()
+    sync.begin()
+    nn.MSELoss()(net(xs), ys).backward()
+    sync.finish()
+    if rank == 0:
+        q.put([None if p.grad is None else p.grad.clone().numpy() for p in net.parameters()])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_equals_global_batch_gradient():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    net = _model(1)
+    net[4].weight.requires_grad_(False)
+    x, y = _batches(1, 8, 8)[0]
+    nn.MSELoss()(net(x), y).backward()
+    for g, p in zip(got, net.parameters()):
+        if p.grad is None:
+            assert g is None
+        else:
+            np.testing.assert_allclose(g, p.grad.numpy(), rtol=1e-5, atol=1e-7)
