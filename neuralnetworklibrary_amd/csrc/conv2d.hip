@@ -3,6 +3,8 @@
 // (Applications/VisionModels/retinanet.py:26-28,43-59,77-97,126-148,187-217,260-295,304,344-348).
 // Layout: activations NHWC, filters KRSC (see include/nnl.h).  MFMA-bound: 2*N*P*Q*K*R*S*C flops per pass.
 #include "igemm_kernels.h"
+#include "igemm_taps.h"
+#include "igemm_wgrad.h"
 
 namespace {
 
@@ -33,6 +35,15 @@ int launch_rowk(IgemmRowkParams p, hipStream_t s) {
 
 template <int MODE>
 int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
+  // tuning hook (tools/bench_conv.py): NNL_IGEMM_TILE=0..3 forces 128x128 / 128x64 / 64x128 / 64x64
+  static const int forced = [] { const char* e = getenv("NNL_IGEMM_TILE"); return e ? atoi(e) : -1; }();
+  switch (forced) {
+    case 0: return launch_rowk<128, 128, 2, 2, MODE>(p, s);
+    case 1: return launch_rowk<128, 64, 2, 2, MODE>(p, s);
+    case 2: return launch_rowk<64, 128, 2, 2, MODE>(p, s);
+    case 3: return launch_rowk<64, 64, 2, 2, MODE>(p, s);
+    default: break;
+  }
   const long b128 = nnl_cdiv(p.M, 128);
   if (p.Nc > 64) {
     if (b128 * nnl_cdiv(p.Nc, 128) >= 400) return launch_rowk<128, 128, 2, 2, MODE>(p, s);
@@ -41,6 +52,50 @@ int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   }
   if (b128 >= 400) return launch_rowk<128, 64, 2, 2, MODE>(p, s);
   return launch_rowk<64, 64, 2, 2, MODE>(p, s);
+}
+
+template <int BM, int BN>
+int launch_taps(IgemmTapsParams p, hipStream_t s) {
+  p.grid_m = (int)nnl_cdiv(p.M, BM);
+  p.grid_n = (int)nnl_cdiv(p.Nc, BN);
+  hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, 16, 2, 2>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+// Tile choice: estimated time = rounds of resident workgroups x per-workgroup work / per-tile MFMA efficiency.
+// Resident workgroups per CU (VGPR/LDS limited) and efficiencies are measured values (tools/bench_conv.py).
+int dispatch_taps(const IgemmTapsParams& p, hipStream_t s) {
+  static const int forced = [] { const char* e = getenv("NNL_IGEMM_TILE"); return e ? atoi(e) : -1; }();
+  struct Cand { int bm, bn, occ; double eff; };
+  static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
+  int best = 0;
+  if (forced >= 0 && forced < 4) {
+    best = forced;
+  } else {
+    double best_t = 1e300;
+    for (int i = 0; i < 4; ++i) {
+      const Cand& c = cands[i];
+      const long blocks = nnl_cdiv(p.M, c.bm) * nnl_cdiv(p.Nc, c.bn);
+      const long slots = 256L * c.occ;
+      const long rounds = nnl_cdiv(blocks, slots);
+      // inside one round the CU is shared by min(occ, blocks/256) workgroups: time ~ (workgroups on the busiest CU) x tile work
+      const long last = blocks - (rounds - 1) * slots;
+      const double per_cu = (double)(rounds - 1) * c.occ + (double)nnl_cdiv(last, 256);
+      const double t = per_cu * c.bm * c.bn / c.eff;
+      if (t < best_t) { best_t = t; best = i; }
+    }
+  }
+  switch (best) {
+    case 0: return launch_taps<128, 128>(p, s);
+    case 1: return launch_taps<128, 64>(p, s);
+    case 2: return launch_taps<64, 128>(p, s);
+    default: return launch_taps<64, 64>(p, s);
+  }
+}
+
+bool taps_ok(long a_elems, long b_elems, int C, int ntaps) {
+  return C % 16 == 0 && ntaps <= IGEMM_MAX_TAPS && a_elems * 4 < (1L << 31) && b_elems * 4 < (1L << 32) - 64;
 }
 
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int RS, int C) {
@@ -87,8 +142,10 @@ struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split; };
 
 WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   WgradPlan pl;
+  static const int forced = [] { const char* e = getenv("NNL_WGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning hook
   pl.bm = (Mc >= 128) ? 128 : 64;
   pl.bn = (Nc >= 128 && pl.bm == 128) ? 128 : 64;
+  if (forced == 0) { pl.bm = 128; pl.bn = 128; } else if (forced == 1) { pl.bm = 128; pl.bn = 64; } else if (forced == 3) { pl.bm = 64; pl.bn = 64; }
   pl.grid_m = (int)nnl_cdiv(Mc, pl.bm);
   pl.grid_n = (int)nnl_cdiv(Nc, pl.bn);
   const long tiles = (long)pl.grid_m * pl.grid_n;
@@ -104,6 +161,31 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   return pl;
 }
 
+bool wgrad_v2_ok(long a_elems, long b_elems, long Kp) {
+  return a_elems * 4 < (1L << 32) - 64 && b_elems * 4 < (1L << 32) - 64 && Kp < (1L << 23);
+}
+
+// launches igemm_wgrad_kernel for plan pl; out = dw or the split-K slab workspace
+int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, long b_elems, int H, int W, int C, int P, int Q,
+                    int R, int S, int stride, int pad, int Mc, int Nc, long Kp, const WgradPlan& pl, hipStream_t s) {
+  IgemmWgradParams q{};
+  q.a = dy; q.b = x; q.y = out;
+  q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
+  q.H = H; q.W = W; q.C = C; q.P = P; q.Q = Q; q.R = R; q.S = S; q.stride = stride; q.pad = pad;
+  q.Mc = Mc; q.Nc = Nc; q.Kp = (int)Kp;
+  q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
+  q.rcp_PQ = 1.0f / (float)(P * Q); q.rcp_Q = 1.0f / (float)Q;
+  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
+  if (pl.bm == 128 && pl.bn == 128)
+    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);
+  else if (pl.bm == 128)
+    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, q);
+  else
+    hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, q);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
 }  // namespace
 
 int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* bias, const float* add, int M, int N,
@@ -113,6 +195,16 @@ int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* 
   p.a = a; p.b = b; p.y = y; p.bias = bias; p.add = add;
   p.N = M; p.H = 1; p.W = 1; p.C = K; p.P = 1; p.Q = 1; p.R = 1; p.S = 1; p.stride = 1; p.pad = 0;
   p.M = M; p.Nc = N; p.Kg = K; p.relu = relu;
+  if (taps_ok((long)M * K, (long)N * K, K, 1)) {
+    IgemmTapsParams q{};
+    q.a = a; q.b = b; q.y = y; q.bias = bias; q.add = add;
+    q.a_bytes = (unsigned)((long)M * K * 4); q.b_bytes = (unsigned)((long)N * K * 4);
+    q.H = 1; q.W = 1; q.C = K; q.P = 1; q.Q = 1; q.in_stride = 1; q.ih0 = 0; q.iw0 = 0;
+    q.OH = 1; q.OW = 1; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
+    q.M = M; q.Nc = N; q.b_row_stride = K; q.relu = relu; q.ntaps = 1;
+    q.tap_dh[0] = 0; q.tap_dw[0] = 0; q.tap_aoff[0] = 0; q.tap_woff[0] = 0;
+    return dispatch_taps(q, s);
+  }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
 }
 
@@ -133,14 +225,19 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
   const size_t need = nnl_internal_gemm_tn_workspace_bytes(Mc, Nc, Kp);
   if (need > 0 && (ws == nullptr || ws_bytes < need)) return nnl_set_error(NNL_ERR_WORKSPACE, "gemm_tn: workspace too small");
   p.y = pl.splits > 1 ? (float*)ws : y;
-  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
-  if (pl.bm == 128 && pl.bn == 128)
-    hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
-  else if (pl.bm == 128)
-    hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
-  NNL_CHECK_LAUNCH();
+  if (wgrad_v2_ok(Kp * Mc, Kp * Nc, Kp)) {
+    int st = launch_wgrad_v2(a, b, p.y, Kp * Mc, Kp * Nc, 1, 1, Nc, 1, 1, 1, 1, 1, 0, Mc, Nc, Kp, pl, s);
+    if (st) return st;
+  } else {
+    const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
+    if (pl.bm == 128 && pl.bn == 128)
+      hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
+    else if (pl.bm == 128)
+      hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
+    NNL_CHECK_LAUNCH();
+  }
   if (pl.splits > 1) {
     const long n4 = (long)Mc * Nc / 4;
     int blocks = (int)nnl_cdiv(n4, 256);
@@ -163,6 +260,24 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
   p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
   p.M = g->N * g->P * g->Q; p.Nc = g->K; p.Kg = g->R * g->S * g->C; p.relu = relu;
   NnlProfScope prof(NNL_PROF_CONV_FWD, s, 2.0 * p.M * (double)p.Nc * p.Kg);
+  const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
+  if (taps_ok(a_elems, b_elems, g->C, g->R * g->S)) {
+    IgemmTapsParams q{};
+    q.a = x; q.b = w; q.y = y; q.bias = bias; q.add = nullptr;
+    q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
+    q.H = g->H; q.W = g->W; q.C = g->C; q.P = g->P; q.Q = g->Q;
+    q.in_stride = g->stride; q.ih0 = -g->pad; q.iw0 = -g->pad;
+    q.OH = g->P; q.OW = g->Q; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
+    q.M = p.M; q.Nc = g->K; q.b_row_stride = g->R * g->S * g->C; q.relu = relu;
+    q.ntaps = g->R * g->S;
+    for (int r = 0; r < g->R; ++r)
+      for (int ss = 0; ss < g->S; ++ss) {
+        const int t = r * g->S + ss;
+        q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
+        q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
+      }
+    return dispatch_taps(q, s);
+  }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
 }
 
@@ -189,6 +304,47 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
   p.R = g->R; p.S = g->S; p.stride = g->stride; p.pad = g->pad;
   p.M = g->N * g->H * g->W; p.Nc = g->C; p.Kg = g->R * g->S * g->K; p.relu = 0;
   NnlProfScope prof(NNL_PROF_CONV_DGRAD, s, 2.0 * g->N * (double)g->P * g->Q * g->K * g->R * g->S * g->C);
+  const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
+  if (taps_ok(a_elems, b_elems, g->K, g->R * g->S) && (g->stride == 1 || g->stride == 2)) {
+    IgemmTapsParams q{};
+    q.a = dy; q.b = wt; q.y = dx; q.bias = nullptr; q.add = nullptr;
+    q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
+    q.H = g->P; q.W = g->Q; q.C = g->K;                     // gathered tensor = dy [N][P][Q][K]
+    q.in_stride = 1; q.ih0 = 0; q.iw0 = 0;
+    q.OH = g->H; q.OW = g->W; q.Nc = g->C; q.b_row_stride = g->R * g->S * g->K; q.relu = 0;
+    const int st2 = g->stride;
+    // one launch per output-parity class (a single class when stride == 1): dx pixel (st*hh + ph, st*ww + pw) receives
+    // exactly the taps r with (ph + pad - r) % st == 0, from dy pixel hh + (ph + pad - r)/st
+    bool need_zero = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1 && need_zero) NNL_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * g->N * g->H * g->W * g->C, s));
+      for (int ph = 0; ph < st2; ++ph)
+        for (int pw = 0; pw < st2; ++pw) {
+          IgemmTapsParams c = q;
+          c.P = (g->H - ph + st2 - 1) / st2; c.Q = (g->W - pw + st2 - 1) / st2;
+          c.out_stride = st2; c.oh0 = ph; c.ow0 = pw;
+          c.M = g->N * c.P * c.Q;
+          int nt = 0;
+          for (int r = 0; r < g->R; ++r) {
+            if ((ph + g->pad - r) % st2 != 0) continue;
+            for (int ss = 0; ss < g->S; ++ss) {
+              if ((pw + g->pad - ss) % st2 != 0) continue;
+              const int dh = (ph + g->pad - r) / st2, dw = (pw + g->pad - ss) / st2;
+              c.tap_dh[nt] = (signed char)dh; c.tap_dw[nt] = (signed char)dw;
+              c.tap_aoff[nt] = (dh * g->Q + dw) * g->K; c.tap_woff[nt] = (r * g->S + ss) * g->K;
+              ++nt;
+            }
+          }
+          c.ntaps = nt;
+          if (c.M <= 0) continue;
+          if (nt == 0) { need_zero = true; continue; }
+          if (pass == 0) continue;                      // first pass only finds out whether dx needs a zero fill
+          int st = dispatch_taps(c, s);
+          if (st) return st;
+        }
+    }
+    return NNL_OK;
+  }
   return dispatch_rowk<IGEMM_MODE_DGRAD>(p, s);
 }
 
@@ -217,14 +373,21 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
     return nnl_set_error(NNL_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
   p.y = pl.splits > 1 ? (float*)workspace : dw;
   NnlProfScope prof(NNL_PROF_CONV_WGRAD, s, 2.0 * p.Kp * (double)p.Mc * p.Nc);
-  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
-  if (pl.bm == 128 && pl.bn == 128)
-    hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
-  else if (pl.bm == 128)
-    hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
-  NNL_CHECK_LAUNCH();
+  const long a_elems = p.Kp * g->K, b_elems = (long)g->N * g->H * g->W * g->C;
+  if (wgrad_v2_ok(a_elems, b_elems, p.Kp)) {
+    int st2 = launch_wgrad_v2(dy, x, p.y, a_elems, b_elems, g->H, g->W, g->C, g->P, g->Q, g->R, g->S, g->stride, g->pad, p.Mc,
+                              p.Nc, p.Kp, pl, s);
+    if (st2) return st2;
+  } else {
+    const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
+    if (pl.bm == 128 && pl.bn == 128)
+      hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
+    else if (pl.bm == 128)
+      hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
+    NNL_CHECK_LAUNCH();
+  }
   if (pl.splits > 1) {
     const long n4 = (long)p.Mc * p.Nc / 4;                 // Nc = R*S*C with C % 4 == 0
     int blocks = (int)nnl_cdiv(n4, 256);

@@ -1,0 +1,203 @@
+// igemm_taps_kernel — second-generation implicit-GEMM (rows gathered through a TAP TABLE) on the exact-fp32 MFMA.
+//
+//   C[m][n] = sum_{t < ntaps} sum_{c < C} A[pix(m) + tap t][c] * B[n][woff_t + c]        (C % BK == 0)
+//
+// Row m enumerates (img, p, q); its base input pixel is (p*in_stride + ih0, q*in_stride + iw0); tap t adds (dh_t, dw_t)
+// and is skipped (zero) when it falls outside [0,H)x[0,W).  The output pixel is (p*out_stride + oh0, q*out_stride + ow0)
+// of an [N][OH][OW][Nc] tensor.  This one kernel covers
+//   * conv forward           : taps = all (r,s), (dh,dw) = (r,s), in_stride = stride, ih0 = -pad;
+//   * dgrad, stride 1        : taps = all (r,s), (dh,dw) = (pad-r, pad-s) over dy, B = W^T [C][R][S][K];
+//   * dgrad, stride 2        : one launch per output-parity class (ph,pw) with only the taps whose parity matches
+//                              (no zero taps fed to the MFMA), out_stride = 2, (oh0,ow0) = (ph,pw);
+//   * Linear / plain NT GEMM : one tap, H = W = P = Q = 1.
+// Differences from the first-generation kernel (igemm_kernels.h): operands are fetched with BUFFER loads (SRD +
+// 32-bit per-lane offset + scalar per-k-step offset; out-of-range lanes return 0, so padding / ragged tiles need no
+// branches), tap validity is a per-row bit mask computed once, the k loop carries only scalar state, and the loop body
+// is a single basic block (the last iteration re-fetches the last tile instead of branching), which lets the compiler
+// interleave the ~20 address instructions with the 32 MFMAs of a k-step.
+#pragma once
+#include "igemm.h"
+
+#define IGEMM_MAX_TAPS 49
+
+struct IgemmTapsParams {
+  const float* a; const float* b; float* y; const float* bias; const float* add;
+  unsigned a_bytes, b_bytes;
+  int H, W, C;
+  int P, Q;
+  int in_stride, ih0, iw0;
+  int OH, OW, out_stride, oh0, ow0;
+  int M, Nc;
+  int b_row_stride;
+  int ntaps;
+  int relu, grid_m, grid_n;
+  int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
+  int tap_woff[IGEMM_MAX_TAPS];        // offset of the tap's C weights inside a B row, elements
+  signed char tap_dh[IGEMM_MAX_TAPS], tap_dw[IGEMM_MAX_TAPS];
+};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(f32x4, v);
+}
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
+  static_assert(WGM * WGN == 4 && BK % 8 == 0, "config");
+  constexpr int BKP = BK + 4;
+  constexpr int KC = BK / 4;
+  constexpr int RPP = 256 / KC;
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(PA >= 1 && PB >= 1 && BM % RPP == 0 && BN % RPP == 0, "tile/thread mapping");
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BKP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int logical = nnl_xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = logical / p.grid_n, tile_n = logical - tile_m * p.grid_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kc = tid % KC, lrow = tid / KC;
+
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
+
+  // ---- per-thread rows: byte offset of the base pixel (+ this thread's 16-B chunk) and the tap validity mask ----
+  int a_off[PA];
+  unsigned long long a_mask[PA];
+  const int PQ = p.P * p.Q;
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int m = m0 + lrow + i * RPP;
+    const bool valid = m < p.M;
+    const int mm = valid ? m : 0;
+    const int n = mm / PQ;
+    const int rem = mm - n * PQ;
+    const int pp = rem / p.Q;
+    const int qq = rem - pp * p.Q;
+    const int h0 = pp * p.in_stride + p.ih0, w0 = qq * p.in_stride + p.iw0;
+    a_off[i] = (((n * p.H + h0) * p.W + w0) * p.C + kc * 4) * 4;
+    unsigned long long mask = 0;
+    if (valid)
+      for (int t = 0; t < p.ntaps; ++t) {
+        const int h = h0 + p.tap_dh[t], w = w0 + p.tap_dw[t];
+        if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) mask |= 1ull << t;
+      }
+    a_mask[i] = mask;
+  }
+  unsigned b_off[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int nr = n0 + lrow + i * RPP;
+    b_off[i] = nr < p.Nc ? (unsigned)(nr * p.b_row_stride + kc * 4) * 4u : 0xFFFFFFFFu;
+  }
+
+  f32x4 ra[PA], rb[PB];
+  auto load_tile = [&](int t, int c0) {
+    const int a_soff = (p.tap_aoff[t] + c0) * 4;         // scalar; may be negative -> folded into the per-lane offset
+    const unsigned b_soff = (unsigned)(p.tap_woff[t] + c0) * 4u;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const bool ok = (a_mask[i] >> t) & 1ull;
+      ra[i] = buf_load4(ra_src, ok ? (unsigned)(a_off[i] + a_soff) : 0xFFFFFFFFu, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, b_off[i], b_soff);
+  };
+  auto store_tile = [&](int buf) {
+    float* As = lds[buf];
+    float* Bs = As + BM * BKP;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * BKP + kc * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + i * RPP) * BKP + kc * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frag_off = (lane & 31) * BKP + (lane >> 5) * 4;
+  auto compute = [&](int buf) {
+    const float* As = lds[buf] + wm * WTM * BKP + frag_off;
+    const float* Bs = lds[buf] + BM * BKP + wn * WTN * BKP + frag_off;
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * BKP + kk * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * BKP + kk * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- k loop: scalar state (tap, channel offset); the body has no branches ----
+  const int csteps = p.C / BK;
+  const int nk = p.ntaps * csteps;
+  int t_nx = 0, c_nx = 0;                     // (tap, c0) of the NEXT tile to fetch
+  load_tile(0, 0);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // advance to tile kt+1, clamped to the last tile (the final iteration re-fetches it; harmless)
+    int c_try = c_nx + BK, t_try = t_nx;
+    if (c_try >= p.C) { c_try = 0; t_try = t_nx + 1; }
+    const bool more = kt + 1 < nk;
+    t_nx = more ? t_try : t_nx;
+    c_nx = more ? c_try : c_nx;
+    load_tile(t_nx, c_nx);                     // buffer loads of tile kt+1 go out FIRST ...
+    __builtin_amdgcn_sched_barrier(0);         // ... (keep the compiler from sinking them behind the MFMAs to save VGPRs)
+    compute(cur);                              // 32 MFMAs per wave cover their latency
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(cur ^ 1);                       // vmcnt wait + ds_write only after the MFMAs are issued
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue ----
+  const int col_l = lane & 31, row_h = (lane >> 5) * 4;
+  const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + col_l;
+    const bool cok = col < p.Nc;
+    const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+        if (cok && row < p.M) {
+          long pix = row;
+          if (!dense_out) {
+            const int n = row / PQ;
+            const int rem = row - n * PQ;
+            const int pp = rem / p.Q;
+            const int qq = rem - pp * p.Q;
+            pix = ((long)n * p.OH + pp * p.out_stride + p.oh0) * p.OW + qq * p.out_stride + p.ow0;
+          }
+          float v = acc[i][j][e] + bv;
+          if (p.add) v += p.add[pix * p.Nc + col];
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[pix * p.Nc + col] = v;
+        }
+      }
+    }
+  }
+}

@@ -1,0 +1,152 @@
+// igemm_wgrad_kernel — second-generation weight-gradient GEMM on the exact-fp32 MFMA:
+//   dW[co][(r,s,ci)] = sum over pixels k=(n,p,q) of dy[k][co] * x[n][p*stride-pad+r][q*stride-pad+s][ci]
+// Both operands are k-major (rows = pixels, channels contiguous): LDS tiles [BK][BM] / [BK][BN], ds_read_b32 fragments.
+// Against the first-generation kernel (igemm_kernels.h: igemm_kmajor_kernel): operands come through BUFFER loads with
+// per-lane 32-bit offsets (invalid pixels / ragged edges / rows past the split get an out-of-range offset and read 0:
+// no branches), the per-row pixel decode uses a float-reciprocal division with a +-1 fix-up instead of two integer
+// divisions, the loads of tile t+1 are pinned ahead of the MFMAs of tile t, and __launch_bounds__ keeps 4-5 waves/SIMD.
+// grid = grid_m * grid_n * splits; split s reduces pixels [s*k_per_split, (s+1)*k_per_split) into its own slab.
+#pragma once
+#include "igemm_taps.h"
+
+struct IgemmWgradParams {
+  const float* a;      // dy [Kp][Mc]
+  const float* b;      // x  [N][H][W][C]
+  float* y;            // [Mc][Nc] or [splits][Mc][Nc]
+  unsigned a_bytes, b_bytes;
+  int H, W, C, P, Q;
+  int R, S, stride, pad;
+  int Mc, Nc, Kp;
+  int splits, k_per_split, grid_m, grid_n;
+  float rcp_PQ, rcp_Q;
+};
+
+template <int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgrad_kernel(const IgemmWgradParams p) {
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  constexpr int CA = BM / 4, CB = BN / 4;
+  constexpr int RA = 256 / CA, RB = 256 / CB;
+  constexpr int PA = BK / RA, PB = BK / RB;
+  static_assert(PA >= 1 && PB >= 1 && BK % RA == 0 && BK % RB == 0, "tile/thread mapping");
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+
+  __shared__ __attribute__((aligned(16))) float lds[2][BK * (BM + BN)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tiles = p.grid_m * p.grid_n;
+  const int split = blockIdx.x / tiles;
+  const int t_id = blockIdx.x - split * tiles;
+  const int tile_n = t_id / p.grid_m, tile_m = t_id - tile_n * p.grid_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(k_begin + p.k_per_split, p.Kp);
+
+  const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
+
+  const int ca = tid % CA, ra_row = tid / CA;
+  const int a_col = m0 + ca * 4;
+  const bool a_cok = a_col < p.Mc;
+  const int cb = tid % CB, rb_row = tid / CB;
+  const int b_col = n0 + cb * 4;
+  const bool b_cok = b_col < p.Nc;
+  const int btap = (b_cok ? b_col : 0) / p.C;
+  const int bc = (b_cok ? b_col : 0) - btap * p.C;
+  const int br = btap / p.S, bs = btap - br * p.S;
+  const int PQ = p.P * p.Q;
+  const int dh = br - p.pad, dw = bs - p.pad;
+
+  f32x4 ra[PA], rb[PB];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const int k = k0 + ra_row + i * RA;
+      const bool ok = a_cok && k < k_end;
+      ra[i] = buf_load4(ra_src, ok ? (unsigned)(k * p.Mc + a_col) * 4u : 0xFFFFFFFFu, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const int k = k0 + rb_row + i * RB;
+      // (n, pp, qq) = decode(k): float-reciprocal quotient, exact after a +-1 correction (k < 2^23)
+      int n = (int)((float)k * p.rcp_PQ);
+      int rem = k - n * PQ;
+      if (rem < 0) { rem += PQ; n -= 1; } else if (rem >= PQ) { rem -= PQ; n += 1; }
+      int pp = (int)((float)rem * p.rcp_Q);
+      int qq = rem - pp * p.Q;
+      if (qq < 0) { qq += p.Q; pp -= 1; } else if (qq >= p.Q) { qq -= p.Q; pp += 1; }
+      const int h = pp * p.stride + dh, w = qq * p.stride + dw;
+      const bool ok = b_cok && k < k_end && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+      rb[i] = buf_load4(rb_src, ok ? (unsigned)(((n * p.H + h) * p.W + w) * p.C + bc) * 4u : 0xFFFFFFFFu, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* As = lds[buf];
+    float* Bs = As + BK * BM;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(As + (ra_row + i * RA) * BM + ca * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Bs + (rb_row + i * RB) * BN + cb * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  auto compute = [&](int buf) {
+    const float* As = lds[buf] + lh * BM + wm * WTM + l31;
+    const float* Bs = lds[buf] + BK * BM + lh * BN + wn * WTN + l31;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = As[kk * 2 * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = Bs[kk * 2 * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (nk > 0) {
+    load_tile(k_begin);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int k_next = k_begin + min(kt + 1, nk - 1) * BK;      // the last iteration re-fetches the last tile (no branch)
+      load_tile(k_next);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  float* out = p.y + (long)split * p.Mc * p.Nc;
+  const int row_h = lh * 4;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * WTN + j * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+        if (col < p.Nc && row < p.Mc) out[(long)row * p.Nc + col] = acc[i][j][e];
+      }
+    }
+  }
+}
