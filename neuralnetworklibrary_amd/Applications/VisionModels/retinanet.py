@@ -22,8 +22,14 @@ __all__ = ['HipConv2d', 'conv3x3', 'BasicBlock', 'Bottleneck', 'PyramidFeatures'
 
 
 class HipConv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters / state_dict) computed by the HIP implicit-GEMM kernels."""
+    """nn.Conv2d (same parameters / state_dict) computed by the HIP implicit-GEMM kernels.  The weight keeps its logical
+    [K,C,R,S] shape but is STORED channels_last (= KRSC, the kernels' filter layout), so no per-step re-layout is needed
+    and the weight gradient comes back in the parameter's own layout; state_dict load / save are unaffected."""
     fuse_relu = False
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x):
         if self.dilation != (1, 1) or self.groups != 1 or self.stride[0] != self.stride[1] \

@@ -115,13 +115,23 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
   }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n4, int splits) {
-  // out[i] = sum_s part[s][i], fixed order => bitwise reproducible; float4 per thread
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 acc = reinterpret_cast<const f32x4*>(part)[i];
-    for (int s = 1; s < splits; ++s) acc += reinterpret_cast<const f32x4*>(part)[(long)s * n4 + i];
-    reinterpret_cast<f32x4*>(out)[i] = acc;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,
+                                                             int splits) {
+  // out[i] = sum_s part[s][i] in a FIXED order (bitwise reproducible).  256 threads = 32 float4 columns x 8 split lanes:
+  // lane l adds slabs l, l+8, ...; the 8 partial sums are then added in lane order through LDS.
+  __shared__ f32x4 red[8][32];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + col;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int s = sl; s < splits; s += 8) acc += reinterpret_cast<const f32x4*>(part)[(long)s * n4 + i];
+  red[sl][col] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+    f32x4 t = red[0][col];
+#pragma unroll
+    for (int l = 1; l < 8; ++l) t += red[l][col];
+    reinterpret_cast<f32x4*>(out)[i] = t;
   }
 }
 
@@ -240,9 +250,7 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
   }
   if (pl.splits > 1) {
     const long n4 = (long)Mc * Nc / 4;
-    int blocks = (int)nnl_cdiv(n4, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)ws, y, n4, pl.splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nnl_cdiv(n4, 32)), dim3(256), 0, s, (const float*)ws, y, n4, pl.splits);
     NNL_CHECK_LAUNCH();
   }
   return NNL_OK;
@@ -390,9 +398,7 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   }
   if (pl.splits > 1) {
     const long n4 = (long)p.Mc * p.Nc / 4;                 // Nc = R*S*C with C % 4 == 0
-    int blocks = (int)nnl_cdiv(n4, 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, (const float*)workspace, dw, n4, pl.splits);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nnl_cdiv(n4, 32)), dim3(256), 0, s, (const float*)workspace, dw, n4, pl.splits);
     NNL_CHECK_LAUNCH();
   }
   return NNL_OK;

@@ -54,7 +54,11 @@ class _Bucket:
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.views, o = [], 0
         for p in params:
-            self.views.append(self.flat[o:o + p.numel()].view(p.shape))
+            # same memory layout as the parameter (conv weights are stored channels_last): copies in and the optimizer's
+            # foreach kernels then see matching strides
+            dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last) if p.dim() == 4 else p.is_contiguous()
+            seg = self.flat[o:o + p.numel()]
+            self.views.append(seg.as_strided(p.shape, p.stride()) if dense else seg.view(p.shape))
             o += p.numel()
         self.pending = len(params)
         self.ready = [False] * len(params)
