@@ -92,8 +92,10 @@ int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv
 size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g);
 int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, const nnl_conv_geom_t* g, void* workspace,
                      size_t workspace_bytes, void* stream);
-/* out[c] = sum_r a[r][c]  (bias gradients of conv / linear layers). */
-int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* stream);
+/* out[c] = sum_r a[r][c]  (bias gradients of conv / linear layers), two fixed-order stages (reproducible). */
+size_t nnl_colsum_workspace_bytes(int64_t rows, int64_t cols);
+int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,
+               void* stream);
 
 /* ---- K2: BatchNorm fused with the residual add and ReLU that follow it ---------------------------------
  * Replaces nn.BatchNorm2d + `out += residual` + ReLU of BasicBlock/Bottleneck.forward (retinanet.py:47-48,53-57,

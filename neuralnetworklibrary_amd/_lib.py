@@ -45,7 +45,8 @@ SIGNATURES = {
     'nnl_conv2d_dgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p]),
     'nnl_conv2d_wgrad_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_wgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, sz, c_p]),
-    'nnl_colsum': (C.c_int, [c_p, c_p, i64, i64, c_p]),
+    'nnl_colsum_workspace_bytes': (sz, [i64, i64]),
+    'nnl_colsum': (C.c_int, [c_p, c_p, i64, i64, c_p, sz, c_p]),
     'nnl_tab_renorm': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, f32, c_p, c_p]),
     'nnl_tab_gather_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, c_p]),
     'nnl_tab_scatter_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i32, i32, i32, i32, c_p]),

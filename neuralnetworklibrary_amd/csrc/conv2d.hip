@@ -135,17 +135,43 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-__global__ void colsum_kernel(const float* __restrict__ a, float* __restrict__ out, long rows, int cols) {
-  // out[c] = sum_r a[r][c]; one block per 64-column strip, 256 threads = 4 row-lanes x 64 columns
+// column sums in two fixed-order stages (bitwise reproducible): stage 1 reduces a chunk of rows per block into
+// part[chunk][col], stage 2 adds the chunks of one column in order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, float* __restrict__ part, long rows,
+                                                              int cols, long rows_per_chunk) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
   float acc = 0.f;
-  if (c < cols)
-    for (long r = rl; r < rows; r += 4) acc += a[r * cols + c];
+  if (c < cols) {
+    long r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {                       // 4 independent loads in flight per lane
+      const float v0 = a[r * cols + c], v1 = a[(r + 4) * cols + c], v2 = a[(r + 8) * cols + c], v3 = a[(r + 12) * cols + c];
+      acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; r < r1; r += 4) acc += a[r * cols + c];
+  }
   red[rl][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (rl == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (rl == 0 && c < cols)
+    part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols, int nchunk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int k = 0; k < nchunk; ++k) acc += part[(long)k * cols + c];
+  out[c] = acc;
+}
+
+int colsum_chunks(long rows) {
+  long n = nnl_cdiv(rows, 64);
+  if (n > 256) n = 256;
+  if (n < 1) n = 1;
+  return (int)n;
 }
 
 struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split; };
@@ -404,11 +430,25 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   return NNL_OK;
 }
 
-extern "C" int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* stream) {
-  NNL_CHECK_ARG(a && out && rows >= 0 && cols > 0 && cols < (1L << 30), "colsum: bad argument");
+extern "C" size_t nnl_colsum_workspace_bytes(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return (size_t)colsum_chunks(rows) * cols * sizeof(float);
+}
+
+extern "C" int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  NNL_CHECK_ARG(a && out && rows > 0 && cols > 0 && cols < (1L << 30), "colsum: bad argument");
+  if (workspace == nullptr || workspace_bytes < nnl_colsum_workspace_bytes(rows, cols))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "colsum: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 4.0 * rows * cols);
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)nnl_cdiv(cols, 64)), dim3(256), 0, s, a, out, (long)rows, (int)cols);
+  const int nchunk = colsum_chunks(rows);
+  const long rpc = nnl_cdiv(nnl_cdiv(rows, nchunk), 4) * 4;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nnl_cdiv(cols, 64), nchunk), dim3(256), 0, s, a, (float*)workspace,
+                     (long)rows, (int)cols, rpc);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nnl_cdiv(cols, 256)), dim3(256), 0, s, (const float*)workspace, out, (int)cols,
+                     nchunk);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

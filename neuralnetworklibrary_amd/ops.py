@@ -153,7 +153,9 @@ class _Conv2d(torch.autograd.Function):
             dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db_full = torch.empty(g.K, dtype=torch.float32, device=dyn.device)
-            check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, stream()))
+            cb = int(lib.nnl_colsum_workspace_bytes(g.N * g.P * g.Q, g.K))
+            cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device)
+            check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, ptr(cws), cb, stream()))
             db = db_full[:K]
         return dx, dw, db, None, None, None
 
