@@ -36,7 +36,7 @@ int launch_rowk(IgemmRowkParams p, hipStream_t s) {
 template <int MODE>
 int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   // tuning hook (tools/bench_conv.py): NNL_IGEMM_TILE=0..3 forces 128x128 / 128x64 / 64x128 / 64x64
-  static const int forced = [] { const char* e = getenv("NNL_IGEMM_TILE"); return e ? atoi(e) : -1; }();
+  const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
   switch (forced) {
     case 0: return launch_rowk<128, 128, 2, 2, MODE>(p, s);
     case 1: return launch_rowk<128, 64, 2, 2, MODE>(p, s);
@@ -54,11 +54,11 @@ int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   return launch_rowk<64, 64, 2, 2, MODE>(p, s);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
-  hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, 16, 2, 2>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -66,7 +66,7 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
 // Tile choice: estimated time = rounds of resident workgroups x per-workgroup work / per-tile MFMA efficiency.
 // Resident workgroups per CU (VGPR/LDS limited) and efficiencies are measured values (tools/bench_conv.py).
 int dispatch_taps(const IgemmTapsParams& p, hipStream_t s) {
-  static const int forced = [] { const char* e = getenv("NNL_IGEMM_TILE"); return e ? atoi(e) : -1; }();
+  const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
   int best = 0;
@@ -90,7 +90,15 @@ int dispatch_taps(const IgemmTapsParams& p, hipStream_t s) {
     case 0: return launch_taps<128, 128>(p, s);
     case 1: return launch_taps<128, 64>(p, s);
     case 2: return launch_taps<64, 128>(p, s);
-    default: return launch_taps<64, 64>(p, s);
+    default: {
+      // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
+      // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
+      const char* e_bk = getenv("NNL_IGEMM_BK32");
+      const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64);
+      const int bk32 = e_bk ? atoi(e_bk) : (blocks64 < 1200);
+      if (bk32 && p.C % 32 == 0) return launch_taps<64, 64, 32>(p, s);
+      return launch_taps<64, 64>(p, s);
+    }
   }
 }
 
@@ -178,7 +186,7 @@ struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split; };
 
 WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   WgradPlan pl;
-  static const int forced = [] { const char* e = getenv("NNL_WGRAD_TILE"); return e ? atoi(e) : -1; }();   // tuning hook
+  const char* e_wt = getenv("NNL_WGRAD_TILE"); const int forced = e_wt ? atoi(e_wt) : -1;   // tuning hook (re-read per call)
   pl.bm = (Mc >= 128) ? 128 : 64;
   pl.bn = (Nc >= 128 && pl.bm == 128) ? 128 : 64;
   if (forced == 0) { pl.bm = 128; pl.bn = 128; } else if (forced == 1) { pl.bm = 128; pl.bn = 64; } else if (forced == 3) { pl.bm = 64; pl.bn = 64; }
@@ -190,7 +198,7 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   long kps = nnl_cdiv(Kp, splits);
-  kps = nnl_cdiv(kps, 16) * 16;
+  kps = nnl_cdiv(kps, 32) * 32;
   splits = nnl_cdiv(Kp, kps);
   pl.splits = (int)splits;
   pl.k_per_split = (int)kps;
@@ -212,12 +220,16 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
   q.rcp_PQ = 1.0f / (float)(P * Q); q.rcp_Q = 1.0f / (float)Q;
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
-  if (pl.bm == 128 && pl.bn == 128)
-    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);
-  else if (pl.bm == 128)
+  const char* e_bk = getenv("NNL_WGRAD_BK32");                       // tuning hook
+  const int bk32 = e_bk ? atoi(e_bk) : 0;
+  if (pl.bm == 128 && pl.bn == 128) {
+    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);   // BK=32 measured -7 % here
+  } else if (pl.bm == 128) {
     hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, q);
-  else
-    hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, q);
+  } else {
+    if (bk32 && pl.k_per_split % 32 == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2>), grid, block, 0, s, q);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, q);
+  }
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

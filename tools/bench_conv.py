@@ -38,10 +38,47 @@ def timeit(fn, iters=10):
     return a.elapsed_time(b) / iters
 
 
+def ab(args):
+    """Interleaved A/B of a tuning env var (the library re-reads it per call): per layer and pass, median of 5 rounds."""
+    import statistics
+    var, vals = args.ab.split('=')
+    vals = vals.split(',')
+    dev, N = 'cuda', args.bs
+    print('%-10s %-6s ' % ('layer', 'pass') + ' '.join('%s=%-4s ms   TF/s |' % (var[-6:], v) for v in vals))
+    totals = {v: 0.0 for v in vals}
+    for name, C, H, K, R, stride, pad, count in LAYERS:
+        g = ops._geom(N, H, H, C, K, R, R, stride, pad)
+        x = torch.randn(N, H, H, C, device=dev); w = torch.randn(K, R, R, C, device=dev) * 0.05
+        y = torch.empty(N, g.P, g.Q, K, device=dev); dy = torch.randn(N, g.P, g.Q, K, device=dev)
+        wt = torch.empty(C, R, R, K, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+        wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ws = torch.empty(max(wsb // 4, 1) * 4, device=dev)
+        check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
+        flop = 2.0 * N * g.P * g.Q * K * R * R * C
+        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, stream())),
+               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, stream())),
+               'wgrad': lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), ws.numel() * 4, stream()))}
+        for pname, fn in fns.items():
+            if name == 'stem7x7' and pname == 'dgrad':
+                continue
+            res = {v: [] for v in vals}
+            for _ in range(5):
+                for v in vals:
+                    os.environ[var] = v
+                    res[v].append(timeit(fn, iters=5))
+            med = {v: statistics.median(res[v]) for v in vals}
+            for v in vals:
+                totals[v] += med[v] * count
+            print('%-10s %-6s ' % (name, pname) + ' '.join('%10.3f %7.1f |' % (med[v], flop / med[v] / 1e9) for v in vals))
+    print('ResNet-34 conv total ms/step: ' + '  '.join('%s=%s: %.2f' % (var, v, totals[v]) for v in vals))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bs', type=int, default=64)
+    ap.add_argument('--ab', default=None, help='A/B in ONE process, interleaved: ENVVAR=v0,v1[,v2] (e.g. NNL_IGEMM_BK32=0,1)')
     args = ap.parse_args()
+    if args.ab:
+        return ab(args)
     dev = 'cuda'
     tot = {'fwd': 0., 'dgrad': 0., 'wgrad': 0.}
     totf = 0.
