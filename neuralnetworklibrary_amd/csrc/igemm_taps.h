@@ -126,9 +126,28 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int frag_off = (lane & 31) * BKP + (lane >> 5) * 4;
+  // When a wave owns a single 32x32 accumulator (64x64 block tile) its MFMAs would form one dependent chain; a second
+  // accumulator for the odd 8-wide k groups makes consecutive MFMAs independent (summed once in the epilogue).
+  constexpr bool kTwoAcc = (TM * TN == 1);
+  f32x16 acc2;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
   auto compute = [&](int buf) {
     const float* As = lds[buf] + wm * WTM * BKP + frag_off;
     const float* Bs = lds[buf] + BM * BKP + wn * WTN * BKP + frag_off;
+    if constexpr (kTwoAcc) {
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; kk += 2) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + kk * 8), b0 = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + kk * 8 + 8), b1 = *reinterpret_cast<const f32x4*>(Bs + kk * 8 + 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc2, 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 8; ++kk) {
       f32x4 af[TM], bf[TN];
@@ -171,6 +190,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   }
 
   // ---- epilogue ----
+  if constexpr (kTwoAcc) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
+  }
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
 #pragma unroll
