@@ -164,17 +164,20 @@ int nnl_retina_loss_bwd(const float* anchors, const float* reg, const float* cla
  * Replaces nn.LSTM(num_layers=1) as called by WeightDropLSTM1.forward (Applications/Text.py:495-513) inside
  * LSTM_Encoder.forward (:543-548): gates_t = gx_t + h_{t-1} W_hh^T, c_t = s(f) c_{t-1} + s(i) tanh(g),
  * h_t = s(o) tanh(c_t), gate order i,f,g,o (torch).  gx [T,B,4H] = x_t W_ih^T + b_ih + b_hh for all t (one big
- * GEMM done by the caller with nnl_conv2d_fwd as a 1x1 conv); w_hh_pad [4H, Hp] = (dropped) W_hh with rows
- * zero-padded to Hp = ceil4(H); h0, c0 [B,H].  Outputs y [T,B,H] (h_t), cy [T,B,H] (c_t) and gates [T,B,4H]
- * (ACTIVATED i,f,g,o) — the last two are saved for backward. */
+ * GEMM done by the caller with nnl_conv2d_fwd as a 1x1 conv).  Padded operands (the GEMM k dimension must be a
+ * multiple of 32): Hp = nnl_lstm_padded_hidden(H) = ceil32(H), Gp = nnl_lstm_padded_gates(H) = ceil32(4H);
+ * w_hh_pad [4H, Hp] = (dropped) W_hh with zero-padded rows; h0, c0 [B,H].  Outputs y [T,B,H] (h_t), cy [T,B,H] (c_t)
+ * and gates [T,B,4H] (ACTIVATED i,f,g,o) — the last two are saved for backward. */
+int64_t nnl_lstm_padded_hidden(int64_t H);
+int64_t nnl_lstm_padded_gates(int64_t H);
 size_t nnl_lstm_workspace_bytes(int64_t B, int64_t H);
 int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
                  float* gates, int64_t T, int64_t B, int64_t H, void* workspace, size_t workspace_bytes, void* stream);
-/* BPTT: dy [T,B,H] (may be NULL), dhT / dcT [B,H] (may be NULL = 0), w_hh_t [H,4H] = W_hh^T.
- * Outputs dgates [T,B,4H] (gradient of the PRE-activation gates = d gx; the caller derives dW_ih, dW_hh, db, dx from
- * it with the GEMM entry points), dh0, dc0 [B,H]. */
+/* BPTT: dy [T,B,H] (may be NULL), dhT / dcT [B,H] (may be NULL = 0), w_hh_t_pad [H, Gp] = W_hh^T with zero-padded rows.
+ * Outputs dgates_pad [T,B,Gp] (columns < 4H: gradient of the PRE-activation gates = d gx; columns >= 4H are not written
+ * and must be zero on entry; the caller derives dW_ih, dW_hh, db, dx from it with the GEMM entry points), dh0, dc0 [B,H]. */
 int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy,
-                 const float* c0, const float* w_hh_t, float* dgates, float* dh0, float* dc0, int64_t T, int64_t B,
+                 const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, int64_t T, int64_t B,
                  int64_t H, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K5b: embedding with per-vocabulary-row dropout mask, fused softmax + cross-entropy -----------------------

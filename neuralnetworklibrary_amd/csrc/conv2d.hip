@@ -58,7 +58,7 @@ template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
-  hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(p.grid_m * p.grid_n), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(p.grid_m * p.grid_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -254,6 +254,22 @@ int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* 
     return dispatch_taps(q, s);
   }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
+}
+
+// y_slabs[s][M][N] = partial products over the s-th range of K (s < splits): for skinny GEMMs (M = batch) whose tile grid
+// cannot fill the chip; the consumer adds the slabs in index order (deterministic).  K % 32 == 0.
+int nnl_internal_gemm_nt_splitk(const float* a, const float* b, float* y_slabs, int M, int N, int K, int splits, hipStream_t s) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || splits < 1 || !taps_ok((long)M * K, (long)N * K, K, 1))
+    return nnl_set_error(NNL_ERR_INVALID_ARG, "gemm_nt_splitk: bad sizes M=%d N=%d K=%d", M, N, K);
+  IgemmTapsParams q{};
+  q.a = a; q.b = b; q.y = y_slabs; q.bias = nullptr; q.add = nullptr;
+  q.a_bytes = (unsigned)((long)M * K * 4); q.b_bytes = (unsigned)((long)N * K * 4);
+  q.H = 1; q.W = 1; q.C = K; q.P = 1; q.Q = 1; q.in_stride = 1; q.ih0 = 0; q.iw0 = 0;
+  q.OH = 1; q.OW = 1; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
+  q.M = M; q.Nc = N; q.b_row_stride = K; q.relu = 0; q.ntaps = 1;
+  q.tap_dh[0] = 0; q.tap_dw[0] = 0; q.tap_aoff[0] = 0; q.tap_woff[0] = 0;
+  q.ksplit = splits; q.slab_stride = (long)M * N;
+  return launch_taps<64, 64, 32>(q, s);
 }
 
 size_t nnl_internal_gemm_tn_workspace_bytes(int Mc, int Nc, long Kp) {

@@ -52,6 +52,7 @@ struct IgemmKmajorParams {
 // (ReLU).  K % 4 == 0.  Used by the per-timestep recurrent GEMMs of the LSTM (lstm.hip).
 int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* bias, const float* add, int M, int N,
                          int K, int relu, hipStream_t s);
+int nnl_internal_gemm_nt_splitk(const float* a, const float* b, float* y_slabs, int M, int N, int K, int splits, hipStream_t s);
 // y[Mc][Nc] = sum_k a[k][Mc] * b[k][Nc]  (both k-major; Mc % 4 == 0, Nc % 4 == 0); split-K workspace as for wgrad.
 size_t nnl_internal_gemm_tn_workspace_bytes(int Mc, int Nc, long Kp);
 int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int Nc, long Kp, void* ws, size_t ws_bytes,

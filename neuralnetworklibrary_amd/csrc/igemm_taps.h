@@ -31,6 +31,8 @@ struct IgemmTapsParams {
   int b_row_stride;
   int ntaps;
   int relu, grid_m, grid_n;
+  int ksplit;                          // >1: blockIdx.y picks a contiguous range of k tiles, result goes to slab y + blockIdx.y*slab_stride
+  long slab_stride;                    //     (no bias / add / ReLU in that mode; the consumer sums the slabs in a fixed order)
   int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
   int tap_woff[IGEMM_MAX_TAPS];        // offset of the tap's C weights inside a B row, elements
   signed char tap_dh[IGEMM_MAX_TAPS], tap_dw[IGEMM_MAX_TAPS];
@@ -167,10 +169,19 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 
   // ---- k loop: scalar state (tap, channel offset); the body has no branches ----
   const int csteps = p.C / BK;
-  const int nk = p.ntaps * csteps;
-  int t_nx = 0, c_nx = 0;                     // (tap, c0) of the NEXT tile to fetch
-  load_tile(0, 0);
-  store_tile(0);
+  const int nk_all = p.ntaps * csteps;
+  int kt0 = 0, nk = nk_all;
+  if (p.ksplit > 1) {                          // split-K: this workgroup reduces k tiles [kt0, kt0 + nk)
+    const int per = (nk_all + p.ksplit - 1) / p.ksplit;
+    kt0 = (int)blockIdx.y * per;
+    nk = min(per, nk_all - kt0);
+    if (nk < 0) nk = 0;
+  }
+  int t_nx = kt0 / csteps, c_nx = (kt0 - t_nx * csteps) * BK;       // (tap, c0) of the NEXT tile to fetch
+  if (nk > 0) {
+    load_tile(t_nx, c_nx);
+    store_tile(0);
+  }
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
   }
+  float* const yout = p.ksplit > 1 ? p.y + (long)blockIdx.y * p.slab_stride : p.y;
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
 #pragma unroll
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
           float v = acc[i][j][e] + bv;
           if (p.add) v += p.add[pix * p.Nc + col];
           if (p.relu) v = fmaxf(v, 0.f);
-          p.y[pix * p.Nc + col] = v;
+          yout[pix * p.Nc + col] = v;
         }
       }
     }

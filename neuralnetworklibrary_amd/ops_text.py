@@ -26,7 +26,7 @@ class _LSTMRecurrence(torch.autograd.Function):
         T, B, G = gx.shape
         H = G // 4
         h0, c0 = _f32c(h0).view(B, H), _f32c(c0).view(B, H)
-        Hp = _ceil4(H)
+        Hp = int(lib.nnl_lstm_padded_hidden(H))
         w_pad = w_hh if Hp == H else F.pad(w_hh, (0, Hp - H))
         dev = gx.device
         y = torch.empty(T, B, H, dtype=torch.float32, device=dev)
@@ -47,9 +47,12 @@ class _LSTMRecurrence(torch.autograd.Function):
         dy = None if dy is None else _f32c(dy)
         dhT = None if dhT is None else _f32c(dhT)
         dcT = None if dcT is None else _f32c(dcT)
+        Gp = int(lib.nnl_lstm_padded_gates(H))
         w_t = torch.empty(H, G, dtype=torch.float32, device=dev)
         check(lib.nnl_conv2d_weight_transpose(ptr(w_hh), ptr(w_t), G, 1, 1, H, stream()))
-        dgates = torch.empty(T, B, G, dtype=torch.float32, device=dev)
+        if Gp != G:
+            w_t = F.pad(w_t, (0, Gp - G))
+        dgates = torch.zeros(T, B, Gp, dtype=torch.float32, device=dev)        # pad columns must be zero
         dh0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         wsb = int(lib.nnl_lstm_workspace_bytes(B, H))
@@ -63,13 +66,13 @@ class _LSTMRecurrence(torch.autograd.Function):
             hprev = torch.cat([h0.view(1, B, H), y[:-1]], 0).view(T * B, H)
             if Hp != H:
                 hprev = F.pad(hprev, (0, Hp - H))
-            g = _lib.ConvGeom(T * B, 1, 1, Hp, G, 1, 1, 1, 0, 1, 1)
-            dwp = torch.empty(G, Hp, dtype=torch.float32, device=dev)
+            g = _lib.ConvGeom(T * B, 1, 1, Hp, Gp, 1, 1, 1, 0, 1, 1)
+            dwp = torch.empty(Gp, Hp, dtype=torch.float32, device=dev)
             wb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
             wws = torch.empty(max(wb // 4, 1), dtype=torch.float32, device=dev)
-            check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, G)), ptr(dwp), g, ptr(wws), wb, stream()))
-            dw = dwp[:, :H] if Hp != H else dwp
-        return dgates, dw, dh0.view_as(h0), dc0.view_as(c0)
+            check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, Gp)), ptr(dwp), g, ptr(wws), wb, stream()))
+            dw = dwp[:G, :H]
+        return dgates[:, :, :G], dw, dh0.view_as(h0), dc0.view_as(c0)
 
 
 def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
