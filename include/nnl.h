@@ -196,6 +196,30 @@ int nnl_softmax_ce_fwd(const float* logits, const int64_t* target, float* lse, f
 int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
                        float* dlogits, int64_t rows, int64_t V, void* stream);
 
+/* ---- K8: fused multi-tensor Optimizer.step ------------------------------------------------------------------------
+ * Replaces Optimizer.step (General/Optimizer.py:58-70): decoupled weight decay X *= 1 - wd_g*lr_g (:60-67), global-norm
+ * clip (:54-56, torch.nn.utils.clip_grad_norm_) and the torch.optim SGD(momentum) / Adam update (General/Learner.py:17-19)
+ * for all parameter tensors at once.  `tensors` is a DEVICE array of n_tensors descriptors; param / grad / state arrays of
+ * one tensor share one dense layout and are indexed flat.  grad == NULL: decay only.  lr and decay (= 1 - wd*lr, or 1)
+ * are per tensor (layer-group learning rates).  (chunk_tensor[c], chunk_off[c]) maps workgroup c to a piece of
+ * nnl_optim_chunk_elems() elements.  kind 0 = SGD (state1 = momentum buffer, zero before the first step; momentum may be
+ * 0), kind 1 = Adam (state1 = exp_avg, state2 = exp_avg_sq, `step` = 1-based step count for the bias corrections).
+ * clip > 0: gradients are scaled by min(1, clip/(||g||_2 + 1e-6)) (also written back to .grad, as clip_grad_norm_ does);
+ * clip_workspace: n_chunks + 2 floats, [0] = coefficient, [1] = total norm on return. */
+typedef struct {
+  float* param;
+  float* grad;
+  float* state1;
+  float* state2;
+  int64_t numel;
+  float lr;
+  float decay;
+} nnl_optim_tensor_t;
+int64_t nnl_optim_chunk_elems(void);
+int nnl_optim_step(const nnl_optim_tensor_t* tensors, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                   int64_t n_chunks, int kind, float momentum, float beta1, float beta2, float eps, int64_t step,
+                   float clip, float* clip_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

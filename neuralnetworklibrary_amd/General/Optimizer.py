@@ -35,6 +35,7 @@ class Optimizer(object):
         self.lr, self.wd, self.bn_wd, self.clip = [0] * self.NL, wd, bn_wd, clip
         self.opt = opt_func([{'params': trainable_params(pg), 'lr': 0} for pg in model.param_groups])
         self.grad_sync = None
+        self._fused = None
 
     def attach_grad_sync(self, grad_sync):
         self.grad_sync = grad_sync
@@ -55,9 +56,33 @@ class Optimizer(object):
         if self.clip:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
 
+    def _fused_stepper(self):
+        """The fused HIP multi-tensor step (K8) when every trainable parameter is a dense fp32 CUDA tensor and the torch
+        optimizer is plain SGD(momentum) / Adam; otherwise None (torch's own kernels run, e.g. in CPU host-logic tests)."""
+        if self._fused is None:
+            self._fused = False
+            import os
+            params = [p for g in self.opt.param_groups for p in g['params']]
+            if params and params[0].is_cuda and os.environ.get('NNL_FUSED_OPTIM', '1') != '0':
+                from ..fused_optim import FusedStep
+                if FusedStep.supported(self.opt, params):
+                    self._fused = FusedStep(self.opt)
+        return self._fused or None
+
     def step(self):
         if self.grad_sync is not None:
             self.grad_sync.finish()
+        fused = self._fused_stepper()
+        if fused is not None and fused.uniform_hyper():
+            groups = self.opt.param_groups
+            lrs = [float(g['lr']) for g in groups]
+            decays = []
+            for i in range(len(groups)):
+                layer, is_bn = i % self.NL, i >= self.NL
+                apply = bool(self.wd) and (not is_bn or self.bn_wd)
+                decays.append(1 - self.wd[layer] * self.lr[layer] if apply else 1.0)
+            fused.step(lrs, decays, self.clip)
+            return
         if self.wd:
             reg_groups = self.opt.param_groups[:self.NL]
             bn_groups = self.opt.param_groups[self.NL:]

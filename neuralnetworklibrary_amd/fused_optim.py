@@ -1,0 +1,119 @@
+"""Host side of the fused multi-tensor optimizer step (K8, nnl_optim_step): builds the device descriptor / chunk tables
+for an `Optimizer` wrapper and runs weight decay + clip + SGD-momentum / Adam for all parameters in 1 (3 with clipping)
+launches.  The torch optimizer object stays the owner of the state tensors (`opt.state[p]` is filled with the tensors the
+kernel updates), so `opt.state_dict()` / `load_state_dict()` — used by Learner.save / load / find_lr — keep working."""
+import numpy as np
+import torch
+import torch.optim as optim
+
+from ._lib import check, lib, ptr, stream
+
+_DESC = np.dtype([('param', '<u8'), ('grad', '<u8'), ('s1', '<u8'), ('s2', '<u8'), ('numel', '<i8'), ('lr', '<f4'), ('decay', '<f4')])
+
+
+def _dense_like(a, b):
+    return a.shape == b.shape and a.stride() == b.stride()
+
+
+class FusedStep:
+    """One instance per Optimizer wrapper; `supported(opt)` says whether the torch optimizer can be replaced."""
+
+    @staticmethod
+    def supported(opt, params):
+        if not params or not all(p.is_cuda and p.dtype == torch.float32 for p in params):
+            return False
+        if not all(p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last)) for p in params):
+            return False
+        g0 = opt.param_groups[0]
+        if isinstance(opt, optim.SGD):
+            return all(g.get('dampening', 0) == 0 and not g.get('nesterov', False) and g.get('weight_decay', 0) == 0
+                       and not g.get('maximize', False) for g in opt.param_groups)
+        if type(opt) is optim.Adam:
+            return all(not g.get('amsgrad', False) and g.get('weight_decay', 0) == 0 and not g.get('maximize', False)
+                       and not g.get('capturable', False) and not torch.is_tensor(g['lr']) for g in opt.param_groups) and 'betas' in g0
+        return False
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.kind = 0 if isinstance(opt, optim.SGD) else 1
+        self.params, self.group_of = [], []
+        for gi, g in enumerate(opt.param_groups):
+            for p in g['params']:
+                self.params.append(p)
+                self.group_of.append(gi)
+        self.device = self.params[0].device
+        chunk = int(lib.nnl_optim_chunk_elems())
+        ct, co = [], []
+        for ti, p in enumerate(self.params):
+            for off in range(0, p.numel(), chunk):
+                ct.append(ti); co.append(off)
+        self.n_chunks = len(ct)
+        self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=self.device)
+        self.chunk_off = torch.tensor(co, dtype=torch.int64, device=self.device)
+        n = len(self.params)
+        self.host = [torch.empty(n * _DESC.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.dev = torch.empty(n * _DESC.itemsize, dtype=torch.uint8, device=self.device)
+        self.clip_ws = torch.empty(self.n_chunks + 2, dtype=torch.float32, device=self.device)
+        self.flip = 0
+        self.steps = 0
+        self._init_state()
+
+    def _init_state(self):
+        "state tensors live in opt.state (created here like torch would create them lazily at the first step)"
+        for p in self.params:
+            st = self.opt.state[p]
+            if self.kind == 0:
+                if st.get('momentum_buffer') is None:
+                    st['momentum_buffer'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            else:
+                if 'exp_avg' not in st:
+                    if not hasattr(self, '_shared_step'):
+                        self._shared_step = torch.tensor(0.0, dtype=torch.float32)
+                    st['step'] = self._shared_step
+                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    def uniform_hyper(self):
+        "momentum / betas / eps must be equal across param groups for the single fused launch"
+        gs = self.opt.param_groups
+        if self.kind == 0:
+            return len({g['momentum'] for g in gs}) == 1
+        return len({(tuple(g['betas']), g['eps']) for g in gs}) == 1
+
+    def step(self, lrs, decays, clip):
+        """lrs / decays: one value per torch param group (decay = 1 - wd*lr or 1.0)."""
+        self._init_state()                                  # state may have been replaced by opt.load_state_dict
+        desc = np.zeros(len(self.params), dtype=_DESC)
+        keep = []
+        for i, p in enumerate(self.params):
+            st = self.opt.state[p]
+            g = p.grad
+            if g is not None and not (_dense_like(g, p) and g.dtype == torch.float32):
+                g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                g2.copy_(g)
+                p.grad = g = g2
+            keep.append(g)
+            desc[i] = (p.data_ptr(), 0 if g is None else g.data_ptr(),
+                       (st['momentum_buffer'] if self.kind == 0 else st['exp_avg']).data_ptr(),
+                       0 if self.kind == 0 else st['exp_avg_sq'].data_ptr(), p.numel(),
+                       lrs[self.group_of[i]], decays[self.group_of[i]])
+        h = self.host[self.flip]
+        self.flip ^= 1
+        h.numpy()[:] = desc.view(np.uint8)
+        self.dev.copy_(h, non_blocking=True)
+        g0 = self.opt.param_groups[0]
+        self.steps += 1
+        if self.kind == 0:
+            mom, b1, b2, eps, step = float(g0['momentum']), 0., 0., 0., self.steps
+        else:
+            st0 = self.opt.state[self.params[0]]
+            step = int(st0['step'].item()) + 1
+            seen = set()
+            for p in self.params:                               # fresh states share ONE counter tensor; loaded ones may not
+                t = self.opt.state[p]['step']
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    t += 1
+            mom, (b1, b2), eps = 0., g0['betas'], g0['eps']
+        check(lib.nnl_optim_step(ptr(self.dev), ptr(self.chunk_tensor), ptr(self.chunk_off), self.n_chunks, self.kind, mom,
+                                 float(b1), float(b2), float(eps), step, float(clip or 0.), ptr(self.clip_ws), stream()))

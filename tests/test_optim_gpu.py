@@ -1,0 +1,72 @@
+"""K8 fused multi-tensor Optimizer.step (nnl_optim_step) against torch.optim + the reference's per-parameter loop
+semantics (decoupled wd on reg / bn groups, global-norm clip, per-layer-group lr), on GPU."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def toy():
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
+    from neuralnetworklibrary_amd.General.Core import separate_bn_layers
+    torch.manual_seed(0)
+    g1 = nn.Sequential(HipConv2d(4, 8, 3, padding=1, bias=False), nn.BatchNorm2d(8), nn.ReLU())   # (a bias before BN has a
+    # theoretically-zero gradient: Adam would amplify its rounding noise to O(lr) and the comparison would be meaningless)
+    g2 = nn.Sequential(nn.Flatten(), nn.Linear(8 * 6 * 6, 37), nn.Tanh(), nn.Linear(37, 1), nn.Flatten(0))
+    net = nn.Sequential(g1, g2)
+    net.layer_groups = [g1, g2]
+    net.param_groups = separate_bn_layers(net.layer_groups)
+    net[1][3].weight.requires_grad_(False)              # a frozen parameter
+    return net.to(DEV)
+
+
+def run(opt_name, fused, kw, steps=4):
+    from neuralnetworklibrary_amd.General.Learner import opt_dict
+    from neuralnetworklibrary_amd.General.Optimizer import Optimizer
+    os.environ['NNL_FUSED_OPTIM'] = '1' if fused else '0'
+    net = toy()
+    o = Optimizer(opt_dict[opt_name], net)
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(16, 4, 6, 6, generator=g).to(DEV), torch.randn(16, generator=g).to(DEV)
+    norms = []
+    for i in range(steps):
+        o.set_params([1e-1 * (i + 1), 3e-2], **kw)
+        o.opt.zero_grad()
+        ((net(x) - y) ** 2).mean().backward()
+        o.step()
+        norms.append(float(net[0][0].weight.grad.norm()))       # clip writes the scaled gradient back
+    assert (o._fused is not None and o._fused is not False) == fused
+    os.environ.pop('NNL_FUSED_OPTIM')
+    return [p.detach().cpu().clone() for p in net.parameters()], norms, o
+
+
+@pytest.mark.parametrize('opt_name,kw', [
+    ('SGD_Mom', dict(wd=[1e-2, 3e-2], bn_wd=True, clip=0.05, momentum=0.8)),
+    ('SGD_Mom', dict(wd=1e-2, bn_wd=False, clip=None)),
+    ('SGD', dict(wd=None, clip=None)),
+    ('Adam', dict(wd=[1e-2, 0.0], bn_wd=True, clip=0.1, betas=(0.8, 0.99))),
+    ('Adam2', dict(wd=None, clip=None)),
+])
+def test_fused_matches_torch_path(opt_name, kw):
+    pf, nf, _ = run(opt_name, True, kw)
+    pt, nt, _ = run(opt_name, False, kw)
+    for a, b in zip(pf, pt):
+        assert_close(a, b, 2e-5, 2e-6, 'param')
+    assert_close(np.array(nf), np.array(nt), 1e-4, 1e-7, 'clipped grad norm')
+
+
+def test_state_dict_round_trip_with_fused_state():
+    """Learner.save/load(saved_optimizer=True) and find_lr rely on opt.state_dict(): the fused path keeps it torch-shaped."""
+    _, _, o = run('Adam', True, dict(wd=1e-3, clip=None), steps=2)
+    sd = o.opt.state_dict()
+    assert set(sd['state'][0]) >= {'step', 'exp_avg', 'exp_avg_sq'} and float(sd['state'][0]['step']) == 2.0
+    o.opt.load_state_dict(sd)
+    _, _, o2 = run('SGD_Mom', True, dict(wd=1e-3, clip=None), steps=2)
+    assert 'momentum_buffer' in o2.opt.state_dict()['state'][0]
