@@ -99,14 +99,18 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('NNL_BENCH_FORCE_DIST') == '1'       # exercise the RCCL path on a 1-GPU box (world_size 1)
+    if world > 1 or force_dist:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     per_gpu_bs = args.bs if args.scaling == 'weak' else max(args.bs // world, 1)
     learner, data = build_learner(device, per_gpu_bs, args.sz, 1234 + 1 + 1000 * rank)
-    if world > 1:
+    if world > 1 or force_dist:
         learner.distribute()
     learner.model.train()
     lr = [1e-3, 3e-3, 1e-2]

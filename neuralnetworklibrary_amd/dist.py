@@ -103,7 +103,8 @@ class GradSync:
         self._active = True
 
     def _launch(self, b):
-        if world_size() > 1:
+        # NNL_DIST_FORCE_ALLREDUCE=1: issue the collective even at world_size 1 (exercises the RCCL call path on a 1-GPU box)
+        if world_size() > 1 or (dist.is_initialized() and os.environ.get('NNL_DIST_FORCE_ALLREDUCE') == '1'):
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
