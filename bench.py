@@ -150,8 +150,16 @@ def main():
     conv_flop = sum(prof[k]['work'] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
     conv_launches = sum(prof[k]['launches'] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of THIS command
+    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); the committed summary is profiles/r1_traffic.json
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
+            traffic = round(json.load(f)['traffic_bytes_per_launch'])
+    except Exception:
+        pass
     roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
+                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                 'kernel': 'igemm_rowk/igemm_kmajor (fp32 MFMA implicit-GEMM conv2d+linear fwd, dgrad, wgrad)',
                 'launches_per_step': conv_launches / max(n_prof, 1),
                 'avg_launch_ms': conv_ms / max(conv_launches, 1),
