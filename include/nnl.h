@@ -203,9 +203,11 @@ int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* 
  * one tensor share one dense layout and are indexed flat.  grad == NULL: decay only.  lr and decay (= 1 - wd*lr, or 1)
  * are per tensor (layer-group learning rates).  (chunk_tensor[c], chunk_off[c]) maps workgroup c to a piece of
  * nnl_optim_chunk_elems() elements.  kind 0 = SGD (state1 = momentum buffer, zero before the first step; momentum may be
- * 0), kind 1 = Adam (state1 = exp_avg, state2 = exp_avg_sq, `step` = 1-based step count for the bias corrections).
- * clip > 0: gradients are scaled by min(1, clip/(||g||_2 + 1e-6)) (also written back to .grad, as clip_grad_norm_ does);
- * clip_workspace: n_chunks + 2 floats, [0] = coefficient, [1] = total norm on return. */
+ * 0), kind 1 = Adam (state1 = exp_avg, state2 = exp_avg_sq).  `hyper` is a DEVICE array of 8 floats {momentum, beta1,
+ * beta2, eps, bc1 = 1-beta1^t, sqrt(bc2) = sqrt(1-beta2^t), clip max_norm, unused}: hyper-parameters are read from
+ * memory so that a captured hipGraph of the whole step can be replayed with new values.  use_clip != 0: gradients are
+ * scaled by min(1, max_norm/(||g||_2 + 1e-6)) (also written back to .grad, as clip_grad_norm_ does); clip_workspace:
+ * n_chunks + 2 floats, [0] = coefficient, [1] = total norm on return. */
 typedef struct {
   float* param;
   float* grad;
@@ -217,8 +219,7 @@ typedef struct {
 } nnl_optim_tensor_t;
 int64_t nnl_optim_chunk_elems(void);
 int nnl_optim_step(const nnl_optim_tensor_t* tensors, const int32_t* chunk_tensor, const int64_t* chunk_off,
-                   int64_t n_chunks, int kind, float momentum, float beta1, float beta2, float eps, int64_t step,
-                   float clip, float* clip_workspace, void* stream);
+                   int64_t n_chunks, int kind, const float* hyper, int use_clip, float* clip_workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,54 @@ def plot_confusion_matrix(cm, classes, normalize=False, title='Confusion matrix'
     plt.tight_layout()
 
 
+def _tensor_leaves(b):
+    "flat list of the tensors of a (possibly nested list) batch; None marks a non-tensor leaf"
+    if torch.is_tensor(b):
+        return [b]
+    if isinstance(b, (list, tuple)):
+        return [t for v in b for t in _tensor_leaves(v)]
+    return [None]
+
+
+def _tree_map(f, b):
+    return f(b) if torch.is_tensor(b) else [_tree_map(f, v) for v in b]
+
+
+class _GraphedStep:
+    """One captured training step for one input signature (Learner.use_graphs)."""
+
+    def __init__(self, warmup):
+        self.left, self.graph, self.x, self.y, self.loss = warmup, None, None, None, None
+
+    def run(self, learner, x_batch, y_batch):
+        opt = learner.optimizer
+        if self.graph is None:
+            if self.left > 0:                         # eager steps first: lazy state (optimizer moments, gather plans,
+                self.left -= 1                        # workspaces) must exist before the capture
+                return None
+            dev = default_device()
+            self.x = _tree_map(lambda t: t.detach().to(dev, copy=True), x_batch)
+            self.y = _tree_map(lambda t: t.detach().to(dev, copy=True), y_batch)
+            if isinstance(x_batch, tuple):
+                self.x = tuple(self.x)
+            opt.opt.zero_grad()
+            opt.prepare_capture()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):             # records; nothing executes until replay()
+                y_pred = learner.predict1minibatch(self.x)
+                self.loss = learner.loss_func(y_pred, self.y)
+                self.loss.backward()
+                opt.step()
+            self.graph, self.opt_capture = graph, opt.captured()
+        else:
+            for dst, src in zip(_tensor_leaves(self.x) + _tensor_leaves(self.y), _tensor_leaves(x_batch) + _tensor_leaves(y_batch)):
+                dst.copy_(src, non_blocking=True)
+            opt.replay_step(self.opt_capture)
+        self.graph.replay()
+        return self.loss.item()
+
+
 class Learner(object):
     """Model + data + optimizer + loss, with fit / fit_cycles / fit_one_cycle / find_lr / evaluate / predict
     (General/Learner.py:64-115 for the arguments and attributes)."""
@@ -97,6 +145,7 @@ class Learner(object):
         self.optimizer = Optimizer(opt_dict[optimizer], self.model) if isinstance(optimizer, str) else optimizer
         self.bn_frozen = None
         self.grad_sync = None
+        self._graph_warmup, self._graphs = None, {}
 
     # ---- data parallelism (new) -----------------------------------------------------
     def distribute(self, bucket_mb=25.0, sync_bn=False):
@@ -108,7 +157,19 @@ class Learner(object):
             nnl_dist.enable_sync_bn(self.model)
         return self
 
+    def use_graphs(self, flag=True, warmup=2):
+        """MI355X addition: capture the WHOLE training step (forward, loss, backward, fused optimizer) in a hipGraph after
+        `warmup` eager steps per input shape and replay it afterwards — for the launch-bound heads (collaborative
+        filtering, structured data: ~100 tiny launches per step) the step time is the host's launch rate otherwise.
+        Learning rate / weight decay / momentum / betas / Adam bias corrections are read from device memory by the fused
+        optimizer kernel, so schedules keep working.  Only for models whose forward is stateless between minibatches
+        (NOT the language model: its carried hidden state is Python-side) and tensor-valued targets; a minibatch of another
+        shape (the ragged last one) runs eagerly.  Invalidated by freeze / unfreeze / load."""
+        self._graph_warmup, self._graphs = (int(warmup) if flag else None), {}
+        return self
+
     def _reattach(self):
+        self._graphs = {}
         if self.grad_sync is not None:
             self.grad_sync.rebuild()
             self.optimizer.attach_grad_sync(self.grad_sync)
@@ -137,6 +198,7 @@ class Learner(object):
             self.model.load_state_dict(state['model_state'])
             if saved_optimizer:
                 self.optimizer.opt.load_state_dict(state['optimizer_state'])
+                self._graphs = {}                     # the optimizer state tensors were replaced
         else:
             print("no file found at '{}'".format(path))
 
@@ -350,6 +412,10 @@ class Learner(object):
             lr_batch = list_mult(lr_batch, bs / full_bs)
         opt = self.optimizer
         opt.set_params(lr_batch, opt.wd, opt.bn_wd, opt.clip, **get_param_dict(mom_batch, betas_batch))
+        if self._graph_warmup is not None:
+            loss = self._graphed_step(x_batch, y_batch)
+            if loss is not None:
+                return loss
         opt.opt.zero_grad()
         if self.grad_sync is not None:
             self.grad_sync.begin()
@@ -358,6 +424,19 @@ class Learner(object):
         loss.backward()
         opt.step()
         return loss.item()
+
+    def _graphed_step(self, x_batch, y_batch):
+        "use_graphs(): replay (or first capture) the step for this input signature; None -> run it eagerly"
+        leaves = _tensor_leaves(x_batch) + _tensor_leaves(y_batch)
+        if any(t is None for t in leaves) or not self.optimizer.graph_capturable() or not self.model.training:
+            return None
+        key = (tuple((tuple(t.shape), t.dtype) for t in leaves), self.optimizer.clip is not None and bool(self.optimizer.clip))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4:
+                return None
+            g = self._graphs[key] = _GraphedStep(self._graph_warmup)
+        return g.run(self, x_batch, y_batch)
 
     @staticmethod
     def display_training_results(col_names, values, run_times):

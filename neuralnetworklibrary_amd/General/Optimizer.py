@@ -69,18 +69,40 @@ class Optimizer(object):
                     self._fused = FusedStep(self.opt)
         return self._fused or None
 
+    def _fused_args(self):
+        "per torch-param-group learning rates and decoupled weight-decay factors (1 - wd_g*lr_g, or 1.0 where it does not apply)"
+        groups = self.opt.param_groups
+        lrs = [float(g['lr']) for g in groups]
+        decays = []
+        for i in range(len(groups)):
+            layer, is_bn = i % self.NL, i >= self.NL
+            apply = bool(self.wd) and (not is_bn or self.bn_wd)
+            decays.append(1 - self.wd[layer] * self.lr[layer] if apply else 1.0)
+        return lrs, decays
+
+    def graph_capturable(self):
+        "True when step() is a fixed sequence of launches whose hyper-parameters are read from device memory"
+        fused = self._fused_stepper()
+        return fused is not None and fused.uniform_hyper() and self.grad_sync is None
+
+    def prepare_capture(self):
+        self._fused.prepare_capture()
+
+    def captured(self):
+        "handle of the step() that was just recorded under stream capture (pass it to replay_step)"
+        return self._fused.last_capture
+
+    def replay_step(self, capture):
+        "Host half of step() when the launches themselves are replayed from a captured hipGraph (Learner.use_graphs)."
+        lrs, decays = self._fused_args()
+        self._fused.replay_update(capture, lrs, decays, self.clip)
+
     def step(self):
         if self.grad_sync is not None:
             self.grad_sync.finish()
         fused = self._fused_stepper()
         if fused is not None and fused.uniform_hyper():
-            groups = self.opt.param_groups
-            lrs = [float(g['lr']) for g in groups]
-            decays = []
-            for i in range(len(groups)):
-                layer, is_bn = i % self.NL, i >= self.NL
-                apply = bool(self.wd) and (not is_bn or self.bn_wd)
-                decays.append(1 - self.wd[layer] * self.lr[layer] if apply else 1.0)
+            lrs, decays = self._fused_args()
             fused.step(lrs, decays, self.clip)
             return
         if self.wd:

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(kBlock) void sqnorm_partial_kernel(const nnl_optim_
 }
 
 // coef[0] = min(1, max_norm / (sqrt(sum partial) + 1e-6))   (torch.nn.utils.clip_grad_norm_), fixed summation order
-__global__ void clip_coef_kernel(const float* __restrict__ partial, int n, float max_norm, float* __restrict__ coef) {
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int n, const float* __restrict__ hyper, float* __restrict__ coef) {
+  const float max_norm = hyper[6];
   __shared__ double red[kBlock];
   double a = 0.0;
   for (int i = threadIdx.x; i < n; i += kBlock) a += (double)partial[i];
@@ -56,8 +57,10 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int n, float
 __global__ __launch_bounds__(kBlock) void optim_step_kernel(const nnl_optim_tensor_t* __restrict__ tensors,
                                                              const int32_t* __restrict__ chunk_tensor,
                                                              const int64_t* __restrict__ chunk_off, const float* __restrict__ coef,
-                                                             int kind, float momentum, float beta1, float beta2, float eps,
-                                                             float bc1, float sqrt_bc2, int write_clipped_grad) {
+                                                             int kind, const float* __restrict__ hyper, int write_clipped_grad) {
+  // hyper-parameters live in device memory (uploaded with the descriptor table) so that a captured hipGraph of the whole
+  // training step can be replayed with new momentum / betas / bias corrections
+  const float momentum = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], bc1 = hyper[4], sqrt_bc2 = hyper[5];
   const nnl_optim_tensor_t t = tensors[chunk_tensor[blockIdx.x]];
   const long off = chunk_off[blockIdx.x];
   const long end = off + kChunk < t.numel ? off + kChunk : t.numel;
@@ -95,30 +98,24 @@ __global__ __launch_bounds__(kBlock) void optim_step_kernel(const nnl_optim_tens
 extern "C" int64_t nnl_optim_chunk_elems(void) { return kChunk; }
 
 extern "C" int nnl_optim_step(const nnl_optim_tensor_t* tensors, const int32_t* chunk_tensor, const int64_t* chunk_off,
-                              int64_t n_chunks, int kind, float momentum, float beta1, float beta2, float eps, int64_t step,
-                              float clip, float* clip_workspace, void* stream) {
-  NNL_CHECK_ARG(tensors && chunk_tensor && chunk_off && n_chunks > 0 && n_chunks < (1L << 31), "optim_step: bad table");
+                              int64_t n_chunks, int kind, const float* hyper, int use_clip, float* clip_workspace, void* stream) {
+  NNL_CHECK_ARG(tensors && chunk_tensor && chunk_off && hyper && n_chunks > 0 && n_chunks < (1L << 31), "optim_step: bad table");
   NNL_CHECK_ARG(kind == 0 || kind == 1, "optim_step: kind must be 0 (SGD) or 1 (Adam)");
-  NNL_CHECK_ARG(!(clip > 0.f) || clip_workspace, "optim_step: clipping needs a workspace of n_chunks + 2 floats");
+  NNL_CHECK_ARG(!use_clip || clip_workspace, "optim_step: clipping needs a workspace of n_chunks + 2 floats");
   hipStream_t s = (hipStream_t)stream;
   NnlProfScope prof(NNL_PROF_OPTIM, s, (double)n_chunks * kChunk * (kind == 0 ? 20.0 : 28.0));
   const float* coef = nullptr;
-  if (clip > 0.f) {
+  if (use_clip) {
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((unsigned)n_chunks), dim3(kBlock), 0, s, tensors, chunk_tensor, chunk_off,
                        clip_workspace + 2);
     NNL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)(clip_workspace + 2), (int)n_chunks, clip,
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)(clip_workspace + 2), (int)n_chunks, hyper,
                        clip_workspace);
     NNL_CHECK_LAUNCH();
     coef = clip_workspace;
   }
-  float bc1 = 1.f, sqrt_bc2 = 1.f;
-  if (kind == 1) {
-    bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-    sqrt_bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  }
   hipLaunchKernelGGL(optim_step_kernel, dim3((unsigned)n_chunks), dim3(kBlock), 0, s, tensors, chunk_tensor, chunk_off, coef, kind,
-                     momentum, beta1, beta2, eps, bc1, sqrt_bc2, clip > 0.f ? 1 : 0);
+                     hyper, use_clip ? 1 : 0);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

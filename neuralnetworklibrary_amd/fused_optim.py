@@ -51,11 +51,15 @@ class FusedStep:
         self.chunk_tensor = torch.tensor(ct, dtype=torch.int32, device=self.device)
         self.chunk_off = torch.tensor(co, dtype=torch.int64, device=self.device)
         n = len(self.params)
-        self.host = [torch.empty(n * _DESC.itemsize, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        self.dev = torch.empty(n * _DESC.itemsize, dtype=torch.uint8, device=self.device)
+        # one upload per step: [n descriptors | 8 floats of hyper-parameters]; two pinned staging buffers alternate so that
+        # step t+1 can be prepared while step t's copy is still in flight
+        self.table_bytes = n * _DESC.itemsize
+        self.host = [torch.empty(self.table_bytes + 32, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.dev = torch.empty(self.table_bytes + 32, dtype=torch.uint8, device=self.device)
         self.clip_ws = torch.empty(self.n_chunks + 2, dtype=torch.float32, device=self.device)
         self.flip = 0
         self.steps = 0
+        self._capture_buf = None            # staging buffer for the next captured step (Learner.use_graphs)
         self._init_state()
 
     def _init_state(self):
@@ -80,6 +84,23 @@ class FusedStep:
             return len({g['momentum'] for g in gs}) == 1
         return len({(tuple(g['betas']), g['eps']) for g in gs}) == 1
 
+    def _advance(self):
+        "bump the step counters; returns the hyper-parameter vector the kernel reads (include/nnl.h, nnl_optim_step)"
+        g0 = self.opt.param_groups[0]
+        self.steps += 1
+        if self.kind == 0:
+            return [float(g0['momentum']), 0., 0., 0., 1., 1.]
+        st0 = self.opt.state[self.params[0]]
+        step = int(st0['step'].item()) + 1
+        seen = set()
+        for p in self.params:                               # fresh states share ONE counter tensor; loaded ones may not
+            t = self.opt.state[p]['step']
+            if id(t) not in seen:
+                seen.add(id(t))
+                t += 1
+        b1, b2 = (float(b) for b in g0['betas'])
+        return [0., b1, b2, float(g0['eps']), 1.0 - b1 ** step, float(np.sqrt(1.0 - b2 ** step))]
+
     def step(self, lrs, decays, clip):
         """lrs / decays: one value per torch param group (decay = 1 - wd*lr or 1.0)."""
         self._init_state()                                  # state may have been replaced by opt.load_state_dict
@@ -97,23 +118,38 @@ class FusedStep:
                        (st['momentum_buffer'] if self.kind == 0 else st['exp_avg']).data_ptr(),
                        0 if self.kind == 0 else st['exp_avg_sq'].data_ptr(), p.numel(),
                        lrs[self.group_of[i]], decays[self.group_of[i]])
-        h = self.host[self.flip]
-        self.flip ^= 1
-        h.numpy()[:] = desc.view(np.uint8)
-        self.dev.copy_(h, non_blocking=True)
-        g0 = self.opt.param_groups[0]
-        self.steps += 1
-        if self.kind == 0:
-            mom, b1, b2, eps, step = float(g0['momentum']), 0., 0., 0., self.steps
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            # the captured H2D copy node re-reads its pinned source at every replay, so each captured step owns one staging
+            # buffer (allocated by prepare_capture(): hipHostMalloc is illegal while capturing); replay_update() rewrites
+            # lr / decay / hyper in it.  `keep` pins the graph-pool gradient tensors the table points at.
+            if self._capture_buf is None:
+                raise RuntimeError("FusedStep.step() under stream capture without prepare_capture()")
+            h, self._capture_buf = self._capture_buf, None
+            self.last_capture = (h, keep)
         else:
-            st0 = self.opt.state[self.params[0]]
-            step = int(st0['step'].item()) + 1
-            seen = set()
-            for p in self.params:                               # fresh states share ONE counter tensor; loaded ones may not
-                t = self.opt.state[p]['step']
-                if id(t) not in seen:
-                    seen.add(id(t))
-                    t += 1
-            mom, (b1, b2), eps = 0., g0['betas'], g0['eps']
-        check(lib.nnl_optim_step(ptr(self.dev), ptr(self.chunk_tensor), ptr(self.chunk_off), self.n_chunks, self.kind, mom,
-                                 float(b1), float(b2), float(eps), step, float(clip or 0.), ptr(self.clip_ws), stream()))
+            h = self.host[self.flip]
+            self.flip ^= 1
+        hn = h.numpy()
+        hn[:self.table_bytes] = desc.view(np.uint8)
+        hn[self.table_bytes:].view(np.float32)[:] = self._advance() + [float(clip or 0.), 0.]
+        self.dev.copy_(h, non_blocking=True)
+        hyper = self.dev.data_ptr() + self.table_bytes
+        check(lib.nnl_optim_step(ptr(self.dev), ptr(self.chunk_tensor), ptr(self.chunk_off), self.n_chunks, self.kind,
+                                 hyper, 1 if clip else 0, ptr(self.clip_ws), stream()))
+
+    def prepare_capture(self):
+        "call before torch.cuda.graph(...) around a step(): allocates the staging buffer that capture will bake in"
+        self._init_state()
+        self._capture_buf = torch.empty(self.table_bytes + 32, dtype=torch.uint8).pin_memory()
+
+    def replay_update(self, capture, lrs, decays, clip):
+        """Before replaying a captured training step (`capture` = last_capture taken right after it was recorded): refresh
+        the per-tensor lr / decay and the hyper-parameter vector in the staging buffer the captured copy node reads
+        (pointers are unchanged: the graph owns the gradient memory)."""
+        hn = capture[0].numpy()
+        d = hn[:self.table_bytes].view(_DESC)
+        g = np.asarray(self.group_of)
+        d['lr'] = np.asarray(lrs, dtype=np.float32)[g]
+        d['decay'] = np.asarray(decays, dtype=np.float32)[g]
+        hn[self.table_bytes:].view(np.float32)[:] = self._advance() + [float(clip or 0.), 0.]

@@ -1,0 +1,90 @@
+"""Learner.use_graphs(): the captured-and-replayed training step must train exactly like the eager step (same kernels,
+hyper-parameters read from device memory), including lr / momentum / betas schedules and the ragged last minibatch."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+class Data:
+    def __init__(self, batches, bs, target_type):
+        self.train_dl, self.val_dl, self.bs, self.target_type = batches, batches[:1], bs, target_type
+
+
+def _train(make, batches, bs, optimizer, graphs, sched, wd, clip=None, **kw):
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    torch.manual_seed(0)
+    net = make()
+    learner = Learner('/tmp/nnl_graph_test', Data(batches, bs, 'cont'), net, optimizer=optimizer)
+    learner.init_optimizer(wd=wd, clip=clip)
+    if graphs:
+        learner.use_graphs(True, warmup=2)
+    learner.model.train()
+    losses = []
+    for i, lr in enumerate(sched):
+        x, y = batches[i % len(batches)]
+        extra = {k: v[i] for k, v in kw.items()}
+        losses.append(learner.train1minibatch(x, y, lr, **extra))
+    n_graphs = sum(g.graph is not None for g in learner._graphs.values())
+    return losses, [p.detach().cpu().numpy().copy() for p in net.parameters()], n_graphs
+
+
+def test_collab_adam_schedule_replay_matches_eager():
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterNet
+    g = torch.Generator().manual_seed(3)
+    def batch(n):
+        return (torch.stack([torch.randint(0, 50, (n,), generator=g), torch.randint(0, 70, (n,), generator=g)], 1).to(DEV),
+                torch.randint(1, 6, (n,), generator=g).float().to(DEV))
+    batches = [batch(64), batch(64), batch(64), batch(17)]            # the last one is ragged -> eager (then its own graph)
+    sched = [1e-2 * (1 + 0.3 * i) for i in range(12)]
+    betas = [(0.9 - 0.01 * i, 0.99) for i in range(12)]
+    make = lambda: CollabFilterNet(50, 70, 12, [0.8, 5.2])
+    le, pe, ne = _train(make, batches, 64, 'Adam', False, sched, 1e-3, betas_batch=betas)
+    lg, pg, ng = _train(make, batches, 64, 'Adam', True, sched, 1e-3, betas_batch=betas)
+    assert ne == 0 and ng >= 1
+    assert_close(np.array(lg), np.array(le), 1e-5, 1e-6, 'losses')
+    for a, b in zip(pg, pe):
+        assert_close(a, b, 1e-4, 1e-6, 'params')
+
+
+def test_tabular_sgd_momentum_clip_replay_matches_eager():
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    cards = [11, 5, 7]
+    rs = np.random.RandomState(5)
+    batches = []
+    for _ in range(3):
+        xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=32) for c in cards], 1).astype(np.int64)).to(DEV)
+        xcont = torch.from_numpy(rs.standard_normal((32, 4)).astype(np.float32)).to(DEV)
+        batches.append(([xcat, xcont], torch.from_numpy(rs.rand(32).astype(np.float32)).to(DEV)))
+    make = lambda: StructuredDataNet('cont', 8, 4, [{i: i for i in range(c)} for c in cards], [24, 1], output_range=[0, 1],
+                                     dropout_levels=(0.0, 0.0, [0, 0.0]))
+    sched = [[3e-2 * (1 + i % 3)] * 2 for i in range(9)]
+    mom = [0.9 - 0.02 * i for i in range(9)]
+    le, pe, _ = _train(make, batches, 32, 'SGD_Mom', False, sched, 1e-2, clip=0.5, mom_batch=mom)
+    lg, pg, ng = _train(make, batches, 32, 'SGD_Mom', True, sched, 1e-2, clip=0.5, mom_batch=mom)
+    assert ng == 1
+    assert_close(np.array(lg), np.array(le), 1e-5, 1e-6, 'losses')
+    for a, b in zip(pg, pe):
+        assert_close(a, b, 1e-4, 1e-6, 'params')
+
+
+def test_graph_is_dropped_on_freeze_and_refused_with_grad_sync():
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterNet
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    batches = [(torch.stack([torch.randint(0, 9, (8,)), torch.randint(0, 9, (8,))], 1).to(DEV), torch.rand(8).to(DEV))]
+    learner = Learner('/tmp/nnl_graph_test', Data(batches, 8, 'cont'), CollabFilterNet(9, 9, 4, None), optimizer='SGD')
+    learner.init_optimizer()
+    learner.use_graphs(True, warmup=1)
+    learner.model.train()
+    for _ in range(3):
+        learner.train1minibatch(*batches[0], 1e-2)
+    assert len(learner._graphs) == 1
+    learner._new_optimizer()
+    assert learner._graphs == {}

@@ -3,7 +3,7 @@
   3 tabular  Rossmann-shape StructuredDataNet bs=1024, fc [1000,500,1], Adam                      samples/s
   4 lm       AWD-LSTM LanguageModelNet 400/1150/3, V=47343, bs=64 bptt=70, Adam, RegSeqCE(2,1)    tokens/s
   5 retina   ObjectDetectionNet(20) R50-FPN 512x512 bs=16, SSD_loss, SGD momentum                 images/s
-Usage: python tools/bench_heads.py [collab tabular lm retina] [--steps 10]"""
+Usage: python tools/bench_heads.py [collab tabular lm retina] [--steps 10] [--graphs]"""
 import argparse
 import json
 import os
@@ -27,8 +27,15 @@ class Data:
         self.__dict__.update(kw)
 
 
+GRAPHS = False
+
+
 def run(name, learner, batches, lr, unit, units_per_step, steps, warmup=3, **kw):
     learner.model.train()
+    if GRAPHS and 'lm' not in name and 'retina' not in name:
+        learner.use_graphs(True)
+        name += ' [hipGraph step]'
+        warmup += 3
     for i in range(warmup):
         learner.train1minibatch(*batches[i % len(batches)], lr, **kw)
     torch.cuda.synchronize()
@@ -116,7 +123,9 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('which', nargs='*', default=['collab', 'tabular', 'lm', 'retina'])
     ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--graphs', action='store_true', help='Learner.use_graphs(): replay the captured step (collab / tabular)')
     a = ap.parse_args()
+    GRAPHS = a.graphs
     from neuralnetworklibrary_amd.General.Core import set_default_device
     set_default_device(DEV)
     for w in a.which:
