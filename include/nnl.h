@@ -104,17 +104,40 @@ int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* wor
  * training!=0: batch statistics (biased variance for the normalisation; running_var gets the unbiased one) and
  *   running = (1-momentum)*running + momentum*batch   (running_* may be NULL: track_running_stats=False);
  * training==0: normalise with running_mean / running_var.
- * y = (x-mean)*invstd*gamma + beta [+ residual] [ReLU].  save_mean/save_invstd [C] are kept for backward. */
+ * y = (x-mean)*invstd*gamma + beta [+ residual] [ReLU].  save_mean/save_invstd [C] are kept for backward.
+ * num_batches_tracked (device int64, may be NULL): nn.BatchNorm's step counter, incremented by the training call. */
 size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C);
 int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
-               int64_t C, float eps, float momentum, int training, int relu, void* workspace,
-               size_t workspace_bytes, void* stream);
+               int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
+               void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy * [y > 0] (if relu);  dbeta = sum g;  dgamma = sum g*xhat;  dres = g (if dres != NULL);
  * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) (training) or gamma*invstd*g (eval). dgamma/dbeta may be NULL. */
 int nnl_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
                const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C,
                int training, int relu, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Cross-replica (synchronised) training-mode BatchNorm for data parallelism (global-batch statistics equal
+ * to the single-GPU reference's).  Split-phase, the host runs the collective in between (neuralnetworklibrary_amd/ops.py):
+ *   fwd:  nnl_bn_sync_stats -> all_gather of `stats` (2C+2 floats per rank) -> nnl_bn_sync_fwd
+ *   bwd:  nnl_bn_sync_bwd_reduce -> all_reduce(sum) of `sums` (2C floats) -> nnl_bn_sync_bwd
+ * stats = {mean_r[C], M2_r[C] = sum (x-mean_r)^2, rows>>16, rows&0xFFFF}; all_stats = [world][2C+2] in rank order, merged
+ * with the pairwise (Chan) update in that order, so all ranks get bit-identical mean / invstd / running statistics.
+ * dgamma / dbeta are this rank's LOCAL sums (the gradient all-reduce averages them like every other parameter);
+ * dx uses the global sums and the global row count. */
+int nnl_bn_sync_stats(const float* x, float* stats, int64_t rows, int64_t C, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int nnl_bn_sync_fwd(const float* x, const float* all_stats, int world, const float* gamma, const float* beta,
+                    const float* residual, float* y, float* save_mean, float* save_invstd, float* running_mean,
+                    float* running_var, int64_t rows, int64_t C, float eps, float momentum, int relu,
+                    int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream);
+int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                           float* sums, int64_t rows, int64_t C, int relu, void* workspace, size_t workspace_bytes,
+                           void* stream);
+int nnl_bn_sync_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+                    const float* invstd, const float* local_sums, const float* global_sums, const float* all_stats,
+                    int world, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C, int relu,
+                    void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K3: categorical-embedding front end of StructuredDataNet --------------------------------------------
  * Replaces, per categorical column j, EmbeddingDrop.forward (General/Layers.py:74-76: nn.Embedding(max_norm=1.5)

@@ -139,34 +139,90 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
   s2 = red[ch][0][1];
 }
 
-// ---- finalize: mean / invstd, running statistics, per-channel scale & shift ----------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ scale, float* __restrict__ shift, long rows, int C, float eps,
-                                   float momentum) {
-  __shared__ float red[4][kFinLanes][2];
-  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
-  float s1, s2;
-  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
-  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
-  const float n = (float)rows;
-  const float m = x[c] + s1 / n;
-  float var = (s2 - s1 * (s1 / n)) / n;
-  var = fmaxf(var, 0.f);
+// tail shared by the finalize kernels: invstd, running statistics (unbiased variance), per-channel scale & shift
+__device__ __forceinline__ void finish_stats(int c, int C, float m, float var, float n, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float* __restrict__ mean,
+                                             float* __restrict__ invstd, float* __restrict__ running_mean,
+                                             float* __restrict__ running_var, float* __restrict__ scale,
+                                             float* __restrict__ shift, float eps, float momentum) {
   const float is = 1.f / sqrtf(var + eps);
   mean[c] = m;
   invstd[c] = is;
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
   if (running_var) {
-    const float unbiased = rows > 1 ? var * (n / (n - 1.f)) : var;
+    const float unbiased = n > 1.f ? var * (n / (n - 1.f)) : var;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
   const float gm = gamma ? gamma[c] : 1.f;
   const float sc = is * gm;
   scale[c] = sc;
   shift[c] = (beta ? beta[c] : 0.f) - m * sc;
+}
+
+// ---- finalize: mean / invstd, running statistics, per-channel scale & shift ----------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale, float* __restrict__ shift, long rows, int C, float eps,
+                                   float momentum, long long* __restrict__ num_batches_tracked) {
+  __shared__ float red[4][kFinLanes][2];
+  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
+  float s1, s2;
+  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
+  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm's counter, without its own launch
+  const float n = (float)rows;
+  const float m = x[c] + s1 / n;
+  float var = (s2 - s1 * (s1 / n)) / n;
+  var = fmaxf(var, 0.f);
+  finish_stats(c, C, m, var, n, gamma, beta, mean, invstd, running_mean, running_var, scale, shift, eps, momentum);
+}
+
+// ---- cross-replica BatchNorm (SyncBN) ---------------------------------------------------------------
+// local statistics of this rank: stats[c] = mean_r, stats[C+c] = M2_r = sum (x - mean_r)^2, stats[2C] / [2C+1] = the row
+// count split as hi*65536 + lo (both exact in fp32).  One all_gather of 2C+2 floats per BN layer.
+__global__ void bn_sync_local_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,
+                                     float* __restrict__ stats, long rows, int C) {
+  __shared__ float red[4][kFinLanes][2];
+  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
+  float s1, s2;
+  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
+  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
+  const float n = (float)rows;
+  stats[c] = x[c] + s1 / n;
+  stats[C + c] = fmaxf(s2 - s1 * (s1 / n), 0.f);
+  if (c == 0) {
+    stats[2 * C] = (float)(rows >> 16);
+    stats[2 * C + 1] = (float)(rows & 0xFFFF);
+  }
+}
+
+__device__ __forceinline__ float sync_count(const float* __restrict__ st, int C) { return st[2 * C] * 65536.f + st[2 * C + 1]; }
+
+// merge the `world` ranks' (mean, M2, n) in rank order with the pairwise update of Chan et al. — every rank computes the
+// bit-identical global mean / variance — then finish exactly like the single-replica finalize
+__global__ void bn_sync_merge_kernel(const float* __restrict__ all_stats, int world, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
+                                     float* __restrict__ running_mean, float* __restrict__ running_var,
+                                     float* __restrict__ scale, float* __restrict__ shift, int C, float eps, float momentum,
+                                     long long* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  const long stride = 2L * C + 2;
+  float n = 0.f, m = 0.f, M2 = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float* st = all_stats + r * stride;
+    const float nr = sync_count(st, C);
+    if (nr <= 0.f) continue;
+    const float nn = n + nr;
+    const float d = st[c] - m;
+    m += d * (nr / nn);
+    M2 += st[C + c] + d * d * (n * (nr / nn));
+    n = nn;
+  }
+  finish_stats(c, C, m, fmaxf(M2 / n, 0.f), n, gamma, beta, mean, invstd, running_mean, running_var, scale, shift, eps, momentum);
 }
 
 __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -319,6 +375,37 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int npart
   }
 }
 
+// SyncBN backward: (a) this rank's (sum g, sum g*xhat) -> sums[2C] (all-reduced by the host), (b) coefficients from the
+// GLOBAL sums and row count; dgamma / dbeta stay LOCAL sums (the gradient all-reduce averages them like every parameter)
+__global__ void bn_sync_bwd_sums_kernel(const float* __restrict__ part, int nparts, float* __restrict__ sums, int C) {
+  __shared__ float red[4][kFinLanes][2];
+  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
+  float s1, s2;
+  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
+  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
+  sums[c] = s1;
+  sums[C + c] = s2;
+}
+
+__global__ void bn_sync_bwd_coef_kernel(const float* __restrict__ local_sums, const float* __restrict__ global_sums,
+                                        const float* __restrict__ all_stats, int world, const float* __restrict__ gamma,
+                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                        float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float n = 0.f;
+  for (int r = 0; r < world; ++r) n += sync_count(all_stats + r * (2L * C + 2), C);
+  if (dbeta) dbeta[c] = local_sums[c];
+  if (dgamma) dgamma[c] = local_sums[C + c];
+  const float s1 = global_sums[c], s2 = global_sums[C + c];
+  const float is = invstd[c], mu = mean[c];
+  const float a = (gamma ? gamma[c] : 1.f) * is;
+  const float bq = -a * is * (s2 / n);
+  coef[c] = a;
+  coef[C + c] = bq;
+  coef[2 * C + c] = -a * (s1 / n) - bq * mu;
+}
+
 // ---- backward pass 2: dx = a*g + b*x + c0 ; dres = g -----------------------------------------------------------------
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -374,8 +461,8 @@ extern "C" size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C) {
 
 extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                           float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
-                          int64_t C, float eps, float momentum, int training, int relu, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_fwd: bad sizes rows=%ld C=%ld", (long)rows, (long)C);
   NNL_CHECK_ARG(x && y && save_mean && save_invstd, "bn_fwd: null pointer");
   NNL_CHECK_ARG(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
@@ -396,7 +483,8 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
       hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, (long)rows, (int)C, sh.L);
     NNL_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
-                       save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps, momentum);
+                       save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps, momentum,
+                       (long long*)num_batches_tracked);
     NNL_CHECK_LAUNCH();
   } else {
     NNL_CHECK_HIP(hipMemcpyAsync(save_mean, running_mean, sizeof(float) * C, hipMemcpyDeviceToDevice, s));
@@ -440,6 +528,115 @@ extern "C" int nnl_bn_bwd(const float* dy, const float* y, const float* x, const
                      dgamma, dbeta, coef, (long)rows, (int)C, training);
   NNL_CHECK_LAUNCH();
   const long total_v = rows * CG;
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
+                       (int)CG, (int)C, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
+                       (int)CG, (int)C, relu);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+// ---- SyncBN entry points (split-phase: the host runs the collective between the two halves) -------------------------
+namespace {
+int launch_stats(const float* x, float* part, long rows, long C, hipStream_t s, Shape& sh) {
+  const int VEC = (C % 4 == 0) ? 4 : 1;
+  sh = make_shape(rows, C / VEC);
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, rows, (int)C, sh.L);
+  else
+    hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, rows, (int)C, sh.L);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+}  // namespace
+
+extern "C" int nnl_bn_sync_stats(const float* x, float* stats, int64_t rows, int64_t C, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24) && x && stats, "bn_sync_stats: bad arguments");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_sync_stats: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * 4.0);
+  Shape sh;
+  int rc = launch_stats(x, (float*)workspace, rows, C, s, sh);
+  if (rc != NNL_OK) return rc;
+  hipLaunchKernelGGL(bn_sync_local_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, (const float*)workspace, sh.gx,
+                     stats, (long)rows, (int)C);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_bn_sync_fwd(const float* x, const float* all_stats, int world, const float* gamma, const float* beta,
+                               const float* residual, float* y, float* save_mean, float* save_invstd, float* running_mean,
+                               float* running_var, int64_t rows, int64_t C, float eps, float momentum, int relu,
+                               int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24) && world > 0, "bn_sync_fwd: bad sizes");
+  NNL_CHECK_ARG(x && y && all_stats && save_mean && save_invstd, "bn_sync_fwd: null pointer");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_sync_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* scale = (float*)workspace + (long)kMaxRowBlocks * C * 2;
+  float* shift = scale + C;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * 8.0 + (residual ? 4.0 * rows * C : 0.0));
+  hipLaunchKernelGGL(bn_sync_merge_kernel, dim3((unsigned)nnl_cdiv(C, 256)), dim3(256), 0, s, all_stats, world, gamma, beta,
+                     save_mean, save_invstd, running_mean, running_var, scale, shift, (int)C, eps, momentum,
+                     (long long*)num_batches_tracked);
+  NNL_CHECK_LAUNCH();
+  const int VEC = (C % 4 == 0) ? 4 : 1;
+  const long CG = C / VEC, total_v = rows * CG;
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
+                       (int)CG, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
+                       (int)CG, relu);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                                      float* sums, int64_t rows, int64_t C, int relu, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+  NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_sync_bwd_reduce: bad sizes");
+  NNL_CHECK_ARG(dy && x && mean && invstd && sums && (y || !relu), "bn_sync_bwd_reduce: null pointer");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_sync_bwd_reduce: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  const int VEC = (C % 4 == 0) ? 4 : 1;
+  const Shape sh = make_shape(rows, C / VEC);
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (relu ? 12.0 : 8.0));
+  if (VEC == 4)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
+                       (int)C, sh.L, relu);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
+                       (int)C, sh.L, relu);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_sync_bwd_sums_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, (const float*)part, sh.gx, sums,
+                     (int)C);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_bn_sync_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+                               const float* invstd, const float* local_sums, const float* global_sums, const float* all_stats,
+                               int world, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C, int relu,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24) && world > 0, "bn_sync_bwd: bad sizes");
+  NNL_CHECK_ARG(dy && x && mean && invstd && dx && local_sums && global_sums && all_stats && (y || !relu), "bn_sync_bwd: null pointer");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_sync_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* coef = (float*)workspace + (long)kMaxRowBlocks * C * 2 + 2 * C;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (relu ? 16.0 : 12.0) + (dres ? 4.0 * rows * C : 0.0));
+  hipLaunchKernelGGL(bn_sync_bwd_coef_kernel, dim3((unsigned)nnl_cdiv(C, 256)), dim3(256), 0, s, local_sums, global_sums, all_stats,
+                     world, gamma, mean, invstd, dgamma, dbeta, coef, (int)C);
+  NNL_CHECK_LAUNCH();
+  const int VEC = (C % 4 == 0) ? 4 : 1;
+  const long CG = C / VEC, total_v = rows * CG;
   if (VEC == 4)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
                        (int)CG, (int)C, relu);

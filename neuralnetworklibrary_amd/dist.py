@@ -9,8 +9,10 @@ of backward is still running on the compute stream (RCCL runs on its own stream)
 Optimizer.step) waits for the collectives, and `param.grad` becomes a view of the averaged flat bucket (no copy back).
 
 Numerics: every rank computes the mean loss of its local shard; averaging the gradients over ranks equals the gradient
-of the global-batch mean when shards have equal size.  BatchNorm uses per-replica batch statistics (standard DDP
-semantics; at the benchmark's 64 images per GPU that is exactly the reference's batch-statistics population).
+of the global-batch mean when shards have equal size.  BatchNorm uses per-replica batch statistics by default (standard
+DDP semantics; at the benchmark's 64 images per GPU that is exactly the reference's batch-statistics population);
+`enable_sync_bn` / `Learner.distribute(sync_bn=True)` switches to global-batch statistics (SyncBN kernels in
+csrc/batchnorm.hip), which reproduces the single-GPU reference on the same GLOBAL minibatch.
 """
 import os
 
@@ -171,7 +173,15 @@ class ShardedBatches:
             yield self._cut(x), self._cut(y)
 
 
-def enable_sync_bn(model):
-    """Cross-replica BatchNorm statistics are not implemented yet (SURVEY.md §8e lists them as a parity-only extra):
-    replicas use local batch statistics.  Kept as an explicit no-op so callers can opt in once it exists."""
+def enable_sync_bn(model, group=None, comm=None):
+    """Mark every BatchNorm module of `model` for cross-replica statistics: in training mode ops.bn_act then
+    normalises with the mean / variance of the GLOBAL batch (all ranks' rows) — what the single-GPU reference computes on
+    the same global minibatch — at the cost of one small all_gather (forward) and one all_reduce (backward) per BN layer.
+    A no-op at world size 1 unless `comm` is given (tests inject a fake communicator)."""
+    from .ops import DistComm
+    if comm is None and world_size() == 1:
+        return model
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.nnl_sync = (group, comm or DistComm)
     return model

@@ -192,7 +192,7 @@ def _rows_view(x):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt):
         require_cuda(x, residual, gamma, beta)
         xm, back = _rows_view(x)
         rows, C = xm.shape
@@ -203,8 +203,8 @@ class _BNAct(torch.autograd.Function):
         wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
         check(lib.nnl_bn_fwd(ptr(xm), ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
-                             ptr(running_var), rows, C, float(eps), float(momentum), int(training), int(relu), ptr(ws),
-                             wsb, stream()))
+                             ptr(running_var), rows, C, float(eps), float(momentum), int(training), int(relu), ptr(nbt),
+                             ptr(ws), wsb, stream()))
         ctx.save_for_backward(xm, y if relu else None, gamma, mean, invstd)
         ctx.cfg = (training, relu, residual is not None, back)
         return back(y)
@@ -223,23 +223,105 @@ class _BNAct(torch.autograd.Function):
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
         check(lib.nnl_bn_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
                              ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
-        return (back(dx), None if dres is None else back(dres), dgamma, dbeta, None, None, None, None, None, None)
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 7
+
+
+def _sync_group_size(group):
+    import torch.distributed as dist
+    return dist.get_world_size(group)
+
+
+class _SyncBNAct(torch.autograd.Function):
+    """Training-mode BatchNorm with statistics over the GLOBAL batch of a data-parallel job: two kernels +
+    one small all_gather forward (2C+2 floats per rank), two kernels + one all_reduce backward (2C floats).  `group` is a
+    torch.distributed process group (None = WORLD); gather_fn / reduce_fn are injectable for single-process tests."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, nbt, group, comm):
+        require_cuda(x, residual, gamma, beta)
+        xm, back = _rows_view(x)
+        rows, C = xm.shape
+        rm = None if residual is None else _rows_view(residual)[0]
+        dev = xm.device
+        wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+        stats = torch.empty(2 * C + 2, dtype=torch.float32, device=dev)
+        check(lib.nnl_bn_sync_stats(ptr(xm), ptr(stats), rows, C, ptr(ws), wsb, stream()))
+        all_stats = comm.all_gather(stats, group)                  # [world, 2C+2], rank order
+        world = all_stats.shape[0]
+        y = torch.empty_like(xm)
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        check(lib.nnl_bn_sync_fwd(ptr(xm), ptr(all_stats), world, ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd),
+                                  ptr(running_mean), ptr(running_var), rows, C, float(eps), float(momentum), int(relu), ptr(nbt),
+                                  ptr(ws), wsb, stream()))
+        ctx.save_for_backward(xm, y if relu else None, gamma, mean, invstd, all_stats)
+        ctx.cfg = (relu, residual is not None, back, group, comm)
+        return back(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, y, gamma, mean, invstd, all_stats = ctx.saved_tensors
+        relu, has_res, back, group, comm = ctx.cfg
+        dym = _rows_view(dy)[0]
+        rows, C = xm.shape
+        dev = xm.device
+        wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+        check(lib.nnl_bn_sync_bwd_reduce(ptr(dym), ptr(y), ptr(xm), ptr(mean), ptr(invstd), ptr(sums), rows, C, int(relu), ptr(ws),
+                                         wsb, stream()))
+        total = comm.all_reduce_sum(sums, group)                   # a new tensor; `sums` keeps the local values
+        dx = torch.empty_like(xm)
+        dres = torch.empty_like(xm) if (has_res and ctx.needs_input_grad[1]) else None
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
+        check(lib.nnl_bn_sync_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(sums), ptr(total),
+                                  ptr(all_stats), int(all_stats.shape[0]), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), rows, C,
+                                  int(relu), ptr(ws), wsb, stream()))
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 8
+
+
+class DistComm:
+    "the two collectives SyncBN needs, over torch.distributed (RCCL on the GPUs of a node; gloo in tests)"
+
+    @staticmethod
+    def all_gather(t, group):
+        import torch.distributed as dist
+        w = dist.get_world_size(group)
+        out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather(list(out.unbind(0)), t, group=group)
+        return out
+
+    @staticmethod
+    def all_reduce_sum(t, group):
+        import torch.distributed as dist
+        out = t.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
 
 
 def bn_act(bn, x, residual=None, relu=True):
     """BatchNorm (train: batch statistics + running-stat update; eval: running stats) -> (+ residual) -> ReLU in the HIP
     kernels of batchnorm.hip: the bn -> `out += residual` -> relu tail of BasicBlock / Bottleneck (reference
     retinanet.py:47-48,53-57,81-95), the stem (:372-373) and the BatchNorm1d layers (General/Layers.py:40).
-    `bn` is the nn.BatchNorm{1,2}d module holding weight / bias / running stats (state_dict unchanged)."""
+    `bn` is the nn.BatchNorm{1,2}d module holding weight / bias / running stats (state_dict unchanged).  A module marked by
+    dist.enable_sync_bn (`bn.nnl_sync = (group, comm)`) uses global-batch statistics in training mode."""
     training = bn.training or (bn.running_mean is None)
-    momentum = 0.0
+    momentum, nbt = 0.0, None
     if bn.training and bn.track_running_stats:
-        if bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
-        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked.item())
+        nbt = bn.num_batches_tracked                       # incremented inside the finalize kernel
+        if bn.momentum is not None:
+            momentum = bn.momentum
+        else:                                              # cumulative moving average: the factor needs the count on the host
+            nbt.add_(1)
+            momentum, nbt = 1.0 / float(nbt.item()), None
     rmean = bn.running_mean if (not training or bn.track_running_stats) else None
     rvar = bn.running_var if (not training or bn.track_running_stats) else None
-    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu)
+    sync = getattr(bn, 'nnl_sync', None)
+    if sync is not None and training:
+        return _SyncBNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, momentum, bn.eps, relu, nbt, sync[0], sync[1])
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt)
 
 
 def concat_pool2d(x):
