@@ -131,7 +131,8 @@ class StructuredDataNet(nn.Module):
         if self.n_cat > 0:
             weights = [e.emb.weight for e in self.embeddings]
             combined, self._plan = ops.tab_embed_concat(xcat_batch, weights, row_masks, cont, cont_mask,
-                                                        self.embeddings[0].emb.max_norm, self._plan)
+                                                        self.embeddings[0].emb.max_norm, self._plan,
+                                                        sync=getattr(self, 'nnl_dp', None))
         else:
             combined = cont if cont_mask is None else cont * cont_mask
         return self.head(combined)

@@ -155,6 +155,7 @@ class Learner(object):
         self.optimizer.attach_grad_sync(self.grad_sync)
         if sync_bn:
             nnl_dist.enable_sync_bn(self.model)
+        nnl_dist.enable_sync_renorm(self.model, capacity=self.data.bs)     # tabular max_norm renorm over all ranks' lookups
         return self
 
     def use_graphs(self, flag=True, warmup=2):

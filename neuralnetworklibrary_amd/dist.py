@@ -19,7 +19,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'GradSync', 'ShardedBatches', 'enable_sync_bn', 'world_size', 'rank']
+__all__ = ['init_from_env', 'GradSync', 'ShardedBatches', 'enable_sync_bn', 'enable_sync_renorm', 'world_size', 'rank']
 
 
 def world_size():
@@ -184,4 +184,18 @@ def enable_sync_bn(model, group=None, comm=None):
     for m in model.modules():
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
             m.nnl_sync = (group, comm or DistComm)
+    return model
+
+
+def enable_sync_renorm(model, capacity, group=None, comm=None):
+    """Data-parallel StructuredDataNet: `nn.Embedding(max_norm=1.5)` renormalises the looked-up rows IN PLACE during the
+    forward (reference General/Layers.py:56-76), so ranks that look up different rows would let the replicated tables drift
+    apart.  Marks the tabular front end to all-gather the step's indices ([capacity, n_cat] int64 per rank; capacity = the
+    per-rank full batch size) and renormalise the union (ops.tab_embed_concat).  No-op at world size 1 unless `comm`."""
+    from .ops import DistComm
+    if comm is None and world_size() == 1:
+        return model
+    for m in model.modules():
+        if hasattr(m, 'embeddings') and hasattr(m, '_plan'):
+            m.nnl_dp = (group, comm or DistComm, int(capacity))
     return model

@@ -340,6 +340,7 @@ class TabularPlan:
         import numpy as np
         dev = weights[0].device
         self.key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights) + (str(dev),)
+        self.sync = None
         card = [int(w.shape[0]) for w in weights]
         dim = [int(w.shape[1]) for w in weights]
         self.ncat, self.cat_width, self.total_rows = len(weights), sum(dim), sum(card)
@@ -379,9 +380,11 @@ class _TabEmbedConcat(torch.autograd.Function):
         row_mask = None if row_mask is None else _f32c(row_mask)
         cont_mask = None if cont_mask is None else _f32c(cont_mask)
         if max_norm is not None:
-            check(lib.nnl_tab_renorm(ptr(xcat), ptr(plan.ptrs), ptr(plan.card), ptr(plan.dim), ptr(plan.row_off),
-                                     ptr(plan.row_table), ptr(plan.flags), bs, plan.ncat, plan.total_rows, float(max_norm),
-                                     ptr(index_error_flag(xcat.device)), stream()))
+            # data parallel: the in-place renorm must hit the rows looked up by ANY rank, or the replicas' tables diverge
+            xren = xcat if plan.sync is None else _global_lookup_indices(xcat, plan.sync)
+            check(lib.nnl_tab_renorm(ptr(xren), ptr(plan.ptrs), ptr(plan.card), ptr(plan.dim), ptr(plan.row_off),
+                                     ptr(plan.row_table), ptr(plan.flags), xren.shape[0], plan.ncat, plan.total_rows,
+                                     float(max_norm), ptr(index_error_flag(xcat.device)), stream()))
         ld = plan.cat_width + n_cont
         out = torch.empty(bs, ld, dtype=torch.float32, device=xcat.device)
         check(lib.nnl_tab_gather_fwd(ptr(xcat), ptr(plan.ptrs), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off),
@@ -409,10 +412,32 @@ class _TabEmbedConcat(torch.autograd.Function):
         return (None, dcont, None, None, None, None) + tuple(grads)
 
 
-def tab_embed_concat(xcat, weights, row_mask=None, cont=None, cont_mask=None, max_norm=None, plan=None):
+def _global_lookup_indices(xcat, sync):
+    """All ranks' categorical indices of this step ([sum of local batch sizes (padded), ncat]) — SURVEY.md §8e: "all-gather of
+    touched embedding indices so max_norm renorm hits the same rows on every rank".  sync = (group, comm, capacity): shards
+    are padded to `capacity` rows (the per-rank full batch size) so the collective has a fixed shape and needs no host
+    synchronisation; padding rows are replaced by a real looked-up row (renorm is idempotent per row)."""
+    group, comm, cap = sync
+    bs, ncat = xcat.shape
+    if bs > cap:
+        raise _lib.NnlError(f'tab_embed_concat: local batch {bs} exceeds the data-parallel capacity {cap}')
+    pad = torch.zeros(cap + 1, ncat, dtype=torch.int64, device=xcat.device)
+    pad[:bs] = xcat
+    pad[cap, 0] = bs
+    g = comm.all_gather(pad, group)                                   # [world, cap + 1, ncat]
+    counts, rows = g[:, cap, 0], g[:, :cap]
+    valid = torch.arange(cap, device=xcat.device)[None, :] < counts[:, None]
+    flat = rows.reshape(-1, ncat)
+    fill = flat[valid.reshape(-1).to(torch.uint8).argmax()]             # first real row of any rank
+    return torch.where(valid.reshape(-1, 1), flat, fill).contiguous()
+
+
+def tab_embed_concat(xcat, weights, row_mask=None, cont=None, cont_mask=None, max_norm=None, plan=None, sync=None):
     """[bs, sum(d_j) + n_cont] = cat_j( W_j[xcat[:,j]] * row_mask[j][:,None] ) ++ cont*cont_mask, after the in-place
-    max_norm renorm of the looked-up rows.  Returns (out, plan)."""
+    max_norm renorm of the looked-up rows (of all ranks' lookups when `sync` = (group, comm, capacity) is given).
+    Returns (out, plan)."""
     plan = TabularPlan.for_weights(weights, plan)
+    plan.sync = sync
     return _TabEmbedConcat.apply(xcat, cont, row_mask, cont_mask, plan, max_norm, *weights), plan
 
 
