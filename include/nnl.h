@@ -80,13 +80,19 @@ typedef struct {
   int32_t P, Q;         /* output spatial size */
 } nnl_conv_geom_t;
 
-/* y = conv(x, w) (+ bias[K]) (then ReLU if relu!=0).  bias may be NULL. */
+/* y = conv(x, w) (+ bias[K]) (then ReLU if relu!=0).  bias may be NULL.
+ * workspace (optional, nnl_conv2d_fwd_workspace_bytes(g); NULL = none): lets the launch use the balanced schedule —
+ * when the tile grid is not a multiple of the 256 CUs, the last tiles (or all of them) are cut into k slices whose
+ * partial slabs are summed in a fixed order (bitwise reproducible run to run). */
+size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g);
 int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
-                   int relu, void* stream);
+                   int relu, void* workspace, size_t workspace_bytes, void* stream);
 /* wt[C,R,S,K] = transpose of w[K,R,S,C] over (K,C): the B operand of dgrad. */
 int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
 /* dx[N,H,W,C] = sum_{r,s,k} dy[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * wt[c,r,s,k] (integral taps only). */
-int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* stream);
+size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g);   /* optional workspace, as for the forward */
+int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* workspace,
+                     size_t workspace_bytes, void* stream);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
  * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */
 size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g);

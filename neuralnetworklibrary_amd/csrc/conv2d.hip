@@ -63,9 +63,114 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
   return NNL_OK;
 }
 
+// ---- balanced schedule for the 64x64 taps kernel (see IgemmTapsParams::bal) --------------------------------------------
+// The plan is a pure function of the GEMM shape, so the *_workspace_bytes() query and the launch agree.
+struct BalPlan {
+  int on, bk, main_ks, n_main_tiles, tail_slices, tail_row0;
+  size_t main_floats, tail_floats;        // workspace: [main slabs][tail slabs]
+};
+
+constexpr int kCUs = 256;
+
+BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
+  BalPlan best{};
+  const char* e = getenv("NNL_IGEMM_BALANCE");
+  if ((e && atoi(e) == 0) || Nc % 4 != 0) return best;
+  const long gm = nnl_cdiv(M, 64), gn = nnl_cdiv(Nc, 64), T = gm * gn;
+  const char* e_bk = getenv("NNL_IGEMM_BK32");
+  const int bk = ((e_bk ? atoi(e_bk) : (T < 1200)) && C % 32 == 0) ? 32 : 16;
+  const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
+  const double c_it = bk == 32 ? 0.60 : 0.30;                          // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
+  const double occ = bk == 32 ? 4 : 8;
+  auto wave_iters = [&](long blocks, long iters) {                     // busiest CU's iterations for `blocks` equal workgroups
+    if (blocks <= 0) return 0.0;
+    const double per = (double)blocks / kCUs;
+    return (per <= occ ? (double)nnl_cdiv(blocks, kCUs) : per + 0.5) * iters;   // one resident wave: ceil; else dynamic refill
+  };
+  const double plain = wave_iters(T, I) * c_it;
+  double best_t = plain * 0.97;                                        // need a >= 3 % predicted win
+  for (int ks = 1; ks <= 4; ks *= 2) {
+    if (I / ks < 8) break;
+    const long units = T * ks;
+    long n_main = ((units / kCUs) * kCUs / ks / gn) * gn;              // main tiles: whole multiples of 256 workgroups, whole tile rows
+    if (n_main > T) n_main = T;
+    const long tail = T - n_main;
+    const long it_main = nnl_cdiv(I, ks);
+    for (int S = 1; S <= 32; S *= 2) {
+      if (tail == 0 && S > 1) break;
+      if (S > 1 && I / S < 4) break;
+      const long it_tail = nnl_cdiv(I, S);
+      const long tail_blocks = tail * S;
+      double t = (wave_iters(n_main * ks, it_main) + wave_iters(tail_blocks, it_tail + (S > 1 ? 2 : 0))) * c_it;
+      const long row0 = (n_main / gn) * 64 < M ? (n_main / gn) * 64 : M;
+      const double main_b = ks > 1 ? (2.0 * ks + 1) * row0 * Nc * 4 : 0;
+      const double tail_b = S > 1 ? (2.0 * S + 1) * (M - row0) * Nc * 4 : 0;
+      t += (main_b + tail_b) / 3.0e6 + (ks > 1 ? 3 : 0) + (S > 1 && tail ? 3 : 0);      // reduce traffic at ~3 TB/s + launch
+      if (t < best_t) {
+        best_t = t;
+        best.on = 1; best.bk = bk; best.main_ks = ks; best.n_main_tiles = (int)n_main; best.tail_slices = tail ? S : 1;
+        best.tail_row0 = (int)row0;
+        best.main_floats = ks > 1 ? (size_t)ks * row0 * Nc : 0;
+        best.tail_floats = (S > 1 && tail) ? (size_t)S * (M - row0) * Nc : 0;
+      }
+    }
+  }
+  if (best.on && best.main_ks == 1 && best.tail_slices == 1) best.on = 0;
+  return best;
+}
+
+size_t balance_workspace_bytes(long M, int Nc, int C, int ntaps) {
+  const BalPlan pl = plan_balance(M, Nc, C, ntaps);
+  return pl.on ? (pl.main_floats + pl.tail_floats) * sizeof(float) : 0;
+}
+
+// out[i] = epilogue( sum_s part[s*slab_stride4 + i] ), fixed order (bitwise reproducible); float4 granularity, Nc % 4 == 0
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, long slab_stride4, int nslabs,
+                                                           float* __restrict__ out, long n4, const float* __restrict__ bias,
+                                                           const float* __restrict__ add, int Nc4, int relu) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 acc = reinterpret_cast<const f32x4*>(part)[i];
+  for (int sl = 1; sl < nslabs; ++sl) acc += reinterpret_cast<const f32x4*>(part)[(long)sl * slab_stride4 + i];
+  if (bias) acc += reinterpret_cast<const f32x4*>(bias)[i % Nc4];
+  if (add) acc += reinterpret_cast<const f32x4*>(add)[i];
+  if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+  reinterpret_cast<f32x4*>(out)[i] = acc;
+}
+
+int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t s) {
+  p.grid_m = (int)nnl_cdiv(p.M, 64);
+  p.grid_n = (int)nnl_cdiv(p.Nc, 64);
+  const int T = p.grid_m * p.grid_n;
+  p.bal = 1; p.main_ks = pl.main_ks; p.n_main_tiles = pl.n_main_tiles; p.tail_slices = pl.tail_slices; p.tail_row0 = pl.tail_row0;
+  p.main_out = ws; p.main_slab_stride = (long)pl.tail_row0 * p.Nc;
+  p.tail_out = ws + pl.main_floats; p.tail_slab_stride = (long)(p.M - pl.tail_row0) * p.Nc;
+  const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
+  if (pl.bk == 32)
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+  NNL_CHECK_LAUNCH();
+  const int Nc4 = p.Nc / 4;
+  if (pl.main_ks > 1 && pl.tail_row0 > 0) {
+    const long n4 = (long)pl.tail_row0 * Nc4;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)nnl_cdiv(n4, 256)), dim3(256), 0, s, (const float*)p.main_out, n4, pl.main_ks,
+                       p.y, n4, p.bias, p.add, Nc4, p.relu);
+    NNL_CHECK_LAUNCH();
+  }
+  if (pl.tail_slices > 1 && p.M > pl.tail_row0) {
+    const long n4 = (long)(p.M - pl.tail_row0) * Nc4;
+    const long off = (long)pl.tail_row0 * p.Nc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)nnl_cdiv(n4, 256)), dim3(256), 0, s, (const float*)p.tail_out, n4,
+                       pl.tail_slices, p.y + off, n4, p.bias, p.add ? p.add + off : nullptr, Nc4, p.relu);
+    NNL_CHECK_LAUNCH();
+  }
+  return NNL_OK;
+}
+
 // Tile choice: estimated time = rounds of resident workgroups x per-workgroup work / per-tile MFMA efficiency.
 // Resident workgroups per CU (VGPR/LDS limited) and efficiencies are measured values (tools/bench_conv.py).
-int dispatch_taps(const IgemmTapsParams& p, hipStream_t s) {
+int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0) {
   const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
@@ -91,6 +196,11 @@ int dispatch_taps(const IgemmTapsParams& p, hipStream_t s) {
     case 1: return launch_taps<128, 64>(p, s);
     case 2: return launch_taps<64, 128>(p, s);
     default: {
+      const bool dense_out = p.out_stride == 1 && p.OH == p.P && p.OW == p.Q && p.oh0 == 0 && p.ow0 == 0 && p.ksplit <= 1;
+      if (ws != nullptr && dense_out) {
+        const BalPlan pl = plan_balance(p.M, p.Nc, p.C, p.ntaps);
+        if (pl.on && ws_bytes >= (pl.main_floats + pl.tail_floats) * sizeof(float)) return launch_balanced(p, pl, (float*)ws, s);
+      }
       // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
       const char* e_bk = getenv("NNL_IGEMM_BK32");
@@ -310,8 +420,22 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
   return NNL_OK;
 }
 
+extern "C" size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g) {
+  if (!g || check_geom(g, "conv2d_fwd_workspace_bytes")) return 0;
+  const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
+  if (!taps_ok(a_elems, b_elems, g->C, g->R * g->S)) return 0;
+  return balance_workspace_bytes((long)g->N * g->P * g->Q, g->K, g->C, g->R * g->S);
+}
+
+extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
+  if (!g || check_geom(g, "conv2d_dgrad_workspace_bytes") || g->stride != 1) return 0;
+  const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
+  if (!taps_ok(a_elems, b_elems, g->K, g->R * g->S)) return 0;
+  return balance_workspace_bytes((long)g->N * g->H * g->W, g->C, g->K, g->R * g->S);
+}
+
 extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
-                              int relu, void* stream) {
+                              int relu, void* workspace, size_t workspace_bytes, void* stream) {
   int st = check_geom(g, "conv2d_fwd");
   if (st) return st;
   NNL_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
@@ -338,7 +462,7 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
         q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
         q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
       }
-    return dispatch_taps(q, s);
+    return dispatch_taps(q, s, workspace, workspace_bytes);
   }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
 }
@@ -353,7 +477,8 @@ extern "C" int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int
   return NNL_OK;
 }
 
-extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* stream) {
+extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   int st = check_geom(g, "conv2d_dgrad");
   if (st) return st;
   NNL_CHECK_ARG(dy && wt && dx, "conv2d_dgrad: null pointer");
@@ -401,7 +526,7 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
           if (c.M <= 0) continue;
           if (nt == 0) { need_zero = true; continue; }
           if (pass == 0) continue;                      // first pass only finds out whether dx needs a zero fill
-          int st = dispatch_taps(c, s);
+          int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes);
           if (st) return st;
         }
     }

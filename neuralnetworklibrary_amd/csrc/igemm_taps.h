@@ -33,6 +33,14 @@ struct IgemmTapsParams {
   int relu, grid_m, grid_n;
   int ksplit;                          // >1: blockIdx.y picks a contiguous range of k tiles, result goes to slab y + blockIdx.y*slab_stride
   long slab_stride;                    //     (no bias / add / ReLU in that mode; the consumer sums the slabs in a fixed order)
+  // Balanced schedule (bal != 0; dense outputs only; grid.x = n_main_tiles*main_ks + n_tail_tiles*tail_slices): on 256 CUs a
+  // grid of e.g. 784 equal tiles leaves 16 CUs with 4 workgroups and 240 with 3 — the launch takes 4 units instead of 3.06.
+  // Tiles [0, n_main_tiles) (a multiple of 256 workgroups) run whole (or in main_ks k slices), the remaining "tail" tiles are
+  // cut into tail_slices short k slices that spread evenly over all CUs; slices write partial slabs that a fixed-order
+  // reduce kernel sums (deterministic).  tail rows start at tail_row0 (n_main_tiles is a multiple of grid_n).
+  int bal, main_ks, n_main_tiles, tail_slices, tail_row0;
+  float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
+  float* tail_out; long tail_slab_stride;      // tail_slices > 1: slabs [tail_slices][M - tail_row0][Nc]
   int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
   int tap_woff[IGEMM_MAX_TAPS];        // offset of the tap's C weights inside a B row, elements
   signed char tap_dh[IGEMM_MAX_TAPS], tap_dw[IGEMM_MAX_TAPS];
@@ -60,7 +68,29 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  const int logical = nnl_xcd_remap(blockIdx.x, gridDim.x);
+  int logical, kslice = 0, nslices = 1, row0 = 0;
+  float* yout = p.y;
+  if (p.bal) {
+    const int nmb = p.n_main_tiles * p.main_ks;
+    if ((int)blockIdx.x < nmb) {
+      const int u = nnl_xcd_remap(blockIdx.x, nmb);
+      logical = u / p.main_ks;
+      kslice = u - logical * p.main_ks;
+      nslices = p.main_ks;
+      if (nslices > 1) yout = p.main_out + (long)kslice * p.main_slab_stride;
+    } else {
+      const int tb = (int)blockIdx.x - nmb;
+      const int t = tb / p.tail_slices;
+      kslice = tb - t * p.tail_slices;
+      logical = p.n_main_tiles + t;
+      nslices = p.tail_slices;
+      if (nslices > 1) { yout = p.tail_out + (long)kslice * p.tail_slab_stride; row0 = p.tail_row0; }
+    }
+  } else {
+    logical = nnl_xcd_remap(blockIdx.x, gridDim.x);
+    if (p.ksplit > 1) { kslice = (int)blockIdx.y; nslices = p.ksplit; yout = p.y + (long)blockIdx.y * p.slab_stride; }
+  }
+  const bool partial = nslices > 1;            // partial sums: no bias / add / ReLU (the reduce kernel applies them)
   const int tile_m = logical / p.grid_n, tile_n = logical - tile_m * p.grid_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kc = tid % KC, lrow = tid / KC;
@@ -171,9 +201,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   const int csteps = p.C / BK;
   const int nk_all = p.ntaps * csteps;
   int kt0 = 0, nk = nk_all;
-  if (p.ksplit > 1) {                          // split-K: this workgroup reduces k tiles [kt0, kt0 + nk)
-    const int per = (nk_all + p.ksplit - 1) / p.ksplit;
-    kt0 = (int)blockIdx.y * per;
+  if (partial) {                               // split-K: this workgroup reduces k tiles [kt0, kt0 + nk)
+    const int per = (nk_all + nslices - 1) / nslices;
+    kt0 = kslice * per;
     nk = min(per, nk_all - kt0);
     if (nk < 0) nk = 0;
   }
@@ -205,14 +235,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
   }
-  float* const yout = p.ksplit > 1 ? p.y + (long)blockIdx.y * p.slab_stride : p.y;
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WTN + j * 32 + col_l;
     const bool cok = col < p.Nc;
-    const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    const float bv = (p.bias != nullptr && cok && !partial) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -228,9 +257,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
             pix = ((long)n * p.OH + pp * p.out_stride + p.oh0) * p.OW + qq * p.out_stride + p.ow0;
           }
           float v = acc[i][j][e] + bv;
-          if (p.add) v += p.add[pix * p.Nc + col];
-          if (p.relu) v = fmaxf(v, 0.f);
-          yout[pix * p.Nc + col] = v;
+          if (!partial) {
+            if (p.add) v += p.add[pix * p.Nc + col];
+            if (p.relu) v = fmaxf(v, 0.f);
+          }
+          yout[(pix - row0) * p.Nc + col] = v;
         }
       }
     }

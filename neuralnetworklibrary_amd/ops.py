@@ -120,7 +120,9 @@ class _Conv2d(torch.autograd.Function):
         g = _geom(N, H, W, C, K, R, S, stride, pad)
         y = torch.empty((N, g.P, g.Q, K), dtype=torch.float32, device=x.device)
         b = None if bias is None else _f32c(bias)
-        check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), stream()))
+        wsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g))         # balanced-schedule slabs (0 when the plain launch is used)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
+        check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, stream()))
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
         ctx.c_in = x.shape[1]
         ctx.save_for_backward(xn, wn, y if relu else None)
@@ -143,7 +145,9 @@ class _Conv2d(torch.autograd.Function):
             wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
             check(lib.nnl_conv2d_weight_transpose(ptr(wn), ptr(wt), g.K, g.R, g.S, g.C, stream()))
             dxn = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyn.device)
-            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, stream()))
+            wsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g))
+            dws = torch.empty(wsb // 4, dtype=torch.float32, device=dyn.device) if wsb else None
+            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(dws), wsb, stream()))
             dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
         if ctx.needs_input_grad[1]:
             dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)

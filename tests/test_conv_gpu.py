@@ -68,3 +68,60 @@ def test_conv2d_linearity_full_size():
     y = ops.conv2d(2.0 * x1 + x2, w, None, 1, 1)
     y12 = 2.0 * ops.conv2d(x1, w, None, 1, 1) + ops.conv2d(x2, w, None, 1, 1)
     assert_close(y, y12, rtol=1e-4, atol=1e-4, msg='linearity')
+
+
+# Balanced schedule (IgemmTapsParams::bal): BASELINE-size grids that are not a multiple of the 256 CUs — tail tiles cut into
+# k slices (layer3), base split-K 2 + tail (layer4), everything-is-tail (small batch), ragged M, and the bias+ReLU epilogue
+# moving into the slab-reduce kernel.  Checked against the plain launch (NNL_IGEMM_BALANCE=0) and torch (GPU fp32 conv is not
+# trusted: compare with the CPU fp32 reference on a slice of the batch).
+BAL_CASES = [
+    (64, 256, 14, 256, 3, 1, 1, False, False),
+    (64, 512, 7, 512, 3, 1, 1, False, False),
+    (64, 128, 28, 128, 3, 1, 1, False, False),
+    (64, 256, 14, 256, 3, 1, 1, True, True),        # bias + ReLU applied by the slab-reduce kernel
+    (63, 256, 14, 256, 3, 1, 1, True, False),       # ragged M: the tail tile row is partial
+    (62, 512, 7, 512, 3, 1, 1, False, False),       # split-K 2 for every tile, no tail
+]
+
+
+@pytest.mark.parametrize('case', BAL_CASES, ids=[str(c) for c in BAL_CASES])
+def test_conv2d_balanced_schedule(case, monkeypatch):
+    from neuralnetworklibrary_amd import ops
+    from neuralnetworklibrary_amd._lib import lib
+    N, C, H, K, R, stride, pad, has_bias, relu = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, C, H, H, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
+    b = torch.randn(K, generator=g) if has_bias else None
+    geom = ops._geom(N, H, H, C, K, R, R, stride, pad)
+    assert lib.nnl_conv2d_fwd_workspace_bytes(geom) > 0, 'case does not exercise the balanced schedule'
+
+    def run():
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        bg = b.to(DEV).requires_grad_(True) if has_bias else None
+        out = ops.conv2d(xg, wg, bg, stride, pad, relu)
+        gd = torch.Generator().manual_seed(8)
+        dy = torch.randn(out.shape, generator=gd).to(DEV)
+        out.backward(dy)
+        return out.detach(), xg.grad, wg.grad, dy
+
+    y_bal, dx_bal, dw_bal, dy = run()
+    y_again = run()[0]
+    assert torch.equal(y_bal, y_again), 'balanced schedule must be bitwise reproducible'
+    monkeypatch.setenv('NNL_IGEMM_BALANCE', '0')
+    assert lib.nnl_conv2d_fwd_workspace_bytes(geom) == 0
+    y_pl, dx_pl, dw_pl, _ = run()
+    monkeypatch.delenv('NNL_IGEMM_BALANCE')
+    sy, sx = y_pl.abs().max().item(), dx_pl.abs().max().item()
+    assert_close(y_bal, y_pl, rtol=1e-5, atol=2e-6 * sy, msg='y balanced vs plain')
+    assert_close(dx_bal, dx_pl, rtol=1e-5, atol=2e-6 * sx, msg='dx balanced vs plain')
+    assert_close(dw_bal, dw_pl, rtol=1e-5, atol=1e-6 * dw_pl.abs().max().item(), msg='dw')
+    # torch CPU fp32 on the last images (they live in the tail tiles) and the first
+    for sl in (slice(0, 2), slice(N - 2, N)):
+        xc = x[sl].clone().requires_grad_(True)
+        ref = F.conv2d(xc, w, b, stride=stride, padding=pad)
+        if relu:
+            ref = F.relu(ref)
+        ref.backward(dy[sl].cpu())
+        assert_close(y_bal[sl], ref, rtol=1e-4, atol=1e-5 * sy, msg='y vs torch')
+        assert_close(dx_bal[sl], xc.grad, rtol=1e-4, atol=1e-5 * sx, msg='dx vs torch')

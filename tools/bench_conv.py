@@ -51,11 +51,13 @@ def ab(args):
         x = torch.randn(N, H, H, C, device=dev); w = torch.randn(K, R, R, C, device=dev) * 0.05
         y = torch.empty(N, g.P, g.Q, K, device=dev); dy = torch.randn(N, g.P, g.Q, K, device=dev)
         wt = torch.empty(C, R, R, K, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+        fwsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g)); fws = torch.empty(max(fwsb // 4, 1), device=dev)
+        dwsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g)); dws = torch.empty(max(dwsb // 4, 1), device=dev)
         wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ws = torch.empty(max(wsb // 4, 1) * 4, device=dev)
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
-        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, stream())),
-               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, stream())),
+        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, stream())),
+               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, ptr(dws), dwsb, stream())),
                'wgrad': lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), ws.numel() * 4, stream()))}
         for pname, fn in fns.items():
             if name == 'stem7x7' and pname == 'dgrad':
@@ -93,12 +95,14 @@ def main():
         wt = torch.empty(C, R, R, K, device=dev)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
+        fwsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g)); fws = torch.empty(max(fwsb // 4, 1), device=dev)
+        dwsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g)); dws = torch.empty(max(dwsb // 4, 1), device=dev)
         wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
         ws = torch.empty(max(wsb // 4, 1), device=dev)
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
-        t_f = timeit(lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, stream())))
+        t_f = timeit(lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, stream())))
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
-        t_d = timeit(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, stream())))
+        t_d = timeit(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, ptr(dws), dwsb, stream())))
         t_w = timeit(lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), wsb, stream())))
         print('%-10s %9.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f' % (
             name, flop / 1e9, t_f, flop / t_f / 1e9, t_d, flop / t_d / 1e9, t_w, flop / t_w / 1e9))

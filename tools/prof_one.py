@@ -22,13 +22,15 @@ g = ops._geom(N, H, H, C, K, R, R, stride, pad)
 x = torch.randn(N, H, H, C, device=dev); w = torch.randn(K, R, R, C, device=dev) * 0.05
 y = torch.empty(N, g.P, g.Q, K, device=dev); dy = torch.randn(N, g.P, g.Q, K, device=dev)
 wt = torch.empty(C, R, R, K, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
+fwsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g)); fws = torch.empty(max(fwsb // 4, 1), device=dev)
+dwsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g)); dws = torch.empty(max(dwsb // 4, 1), device=dev)
 wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ws = torch.empty(max(wsb // 4, 1), device=dev)
 check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
 for _ in range(a.iters):
     if a.which == 'fwd':
-        check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, stream()))
+        check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, stream()))
     elif a.which == 'dgrad':
-        check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, stream()))
+        check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, ptr(dws), dwsb, stream()))
     else:
         check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), wsb, stream()))
 torch.cuda.synchronize()
