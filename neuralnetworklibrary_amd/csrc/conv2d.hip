@@ -81,14 +81,15 @@ BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
   const int bk = ((e_bk ? atoi(e_bk) : (T < 1200)) && C % 32 == 0) ? 32 : 16;
   const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
   const double c_it = bk == 32 ? 0.60 : 0.30;                          // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
-  const double occ = bk == 32 ? 4 : 8;
+  const double occ = bk == 32 ? 4 : 6;                                 // resident workgroups per CU (LDS- / VGPR-limited)
   auto wave_iters = [&](long blocks, long iters) {                     // busiest CU's iterations for `blocks` equal workgroups
     if (blocks <= 0) return 0.0;
-    const double per = (double)blocks / kCUs;
-    return (per <= occ ? (double)nnl_cdiv(blocks, kCUs) : per + 0.5) * iters;   // one resident wave: ceil; else dynamic refill
+    const long cap = (long)occ * kCUs;                                 // full residency waves, then the remainder on top
+    const long full = blocks / cap, rem = blocks - full * cap;         // (measured: 1568 workgroups at occupancy 6 take 7 units)
+    return (double)(full * (long)occ + nnl_cdiv(rem, kCUs)) * iters;
   };
   const double plain = wave_iters(T, I) * c_it;
-  double best_t = plain * 0.97;                                        // need a >= 3 % predicted win
+  double best_t = plain * ((e && atoi(e) == 2) ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
   for (int ks = 1; ks <= 4; ks *= 2) {
     if (I / ks < 8) break;
     const long units = T * ks;
@@ -105,7 +106,7 @@ BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
       const long row0 = (n_main / gn) * 64 < M ? (n_main / gn) * 64 : M;
       const double main_b = ks > 1 ? (2.0 * ks + 1) * row0 * Nc * 4 : 0;
       const double tail_b = S > 1 ? (2.0 * S + 1) * (M - row0) * Nc * 4 : 0;
-      t += (main_b + tail_b) / 3.0e6 + (ks > 1 ? 3 : 0) + (S > 1 && tail ? 3 : 0);      // reduce traffic at ~3 TB/s + launch
+      t += (main_b + tail_b) / 4.0e6 + (ks > 1 ? 1 : 0) + (S > 1 && tail ? 1 : 0);      // reduce traffic at ~4 TB/s + launch gap
       if (t < best_t) {
         best_t = t;
         best.on = 1; best.bk = bk; best.main_ks = ks; best.n_main_tiles = (int)n_main; best.tail_slices = tail ? S : 1;
@@ -303,13 +304,22 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   pl.grid_m = (int)nnl_cdiv(Mc, pl.bm);
   pl.grid_n = (int)nnl_cdiv(Nc, pl.bn);
   const long tiles = (long)pl.grid_m * pl.grid_n;
-  long splits = nnl_cdiv(1024, tiles);
   const long max_splits = Kp / 256 > 0 ? Kp / 256 : 1;    // at least 256 pixels (16 k-steps) per split
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  long kps = nnl_cdiv(Kp, splits);
-  kps = nnl_cdiv(kps, 32) * 32;
-  splits = nnl_cdiv(Kp, kps);
+  // Search the split count around ~4 workgroups per CU for the shortest busiest-CU time: all workgroups are resident at
+  // once (occupancy 5), so the launch lasts ceil(blocks/256) x (pixels per split); rounding k_per_split to 32 and a short
+  // last split are accounted for by using the real split length.  The slab reduce costs (2*splits+1) x |dw| bytes.
+  long splits = 1, kps = nnl_cdiv(Kp, 32) * 32;
+  double best_t = 1e300;
+  const double us_per_px = (double)pl.bm * pl.bn * 2.0 / 441e3;            // one workgroup-pixel at ~113 TF/s / 256 CUs
+  for (long sp = 1; sp <= max_splits && tiles * sp <= 256 * 5; ++sp) {
+    const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32) * 32;
+    const long rs = nnl_cdiv(Kp, k1);
+    if (rs != sp) continue;                                               // same plan as a smaller sp
+    const long per_cu = nnl_cdiv(tiles * rs, 256);
+    const double starve = per_cu < 4 ? pow(4.0 / per_cu, 0.3) : 1.0;      // < 4 workgroups per CU cannot hide the load latency
+    const double t = (double)per_cu * k1 * us_per_px * starve + (rs > 1 ? (2.0 * rs + 1) * Mc * Nc * 4 / 3.0e6 + 3 : 0);
+    if (t < best_t) { best_t = t; splits = rs; kps = k1; }
+  }
   pl.splits = (int)splits;
   pl.k_per_split = (int)kps;
   return pl;
