@@ -145,6 +145,21 @@ int nnl_bn_sync_bwd(const float* dy, const float* y, const float* x, const float
                     int world, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C, int relu,
                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- pooling of the vision path (NHWC, C % 4 == 0 for maxpool) ---------------------------------------------------------
+ * nn.MaxPool2d(ksize, stride, pad) of the ResNet stem (Applications/VisionModels/retinanet.py:307,374; torchvision
+ * resnet.maxpool) with torch's tie rule — `if ((val > max) || isnan(val))` in (kh, kw) scan order.  idx [N,P,Q,C] uint8 =
+ * kh*ksize + kw of the winning tap, kept for the backward, which GATHERS (each input pixel sums dy over the windows whose
+ * arg-max it is): no atomics, bitwise reproducible. */
+int nnl_maxpool2d_fwd(const float* x, float* y, uint8_t* idx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t P,
+                      int64_t Q, int ksize, int stride, int pad, void* stream);
+int nnl_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N, int64_t H, int64_t W, int64_t C,
+                      int64_t P, int64_t Q, int ksize, int stride, int pad, void* stream);
+/* AdaptiveConcatPool2d (General/Layers.py:78-87): out[n, 0:C] = max over the HW pixels, out[n, C:2C] = their mean;
+ * argmax [N,C] int32 = pixel index torch's adaptive_max_pool2d would report (first maximum / last NaN); the backward sends
+ * dout[:, :C] to that pixel and dout[:, C:]/HW to every pixel. */
+int nnl_concat_pool_fwd(const float* x, float* out, int32_t* argmax, int64_t N, int64_t HW, int64_t C, void* stream);
+int nnl_concat_pool_bwd(const float* dout, const int32_t* argmax, float* dx, int64_t N, int64_t HW, int64_t C, void* stream);
+
 /* ---- K3: categorical-embedding front end of StructuredDataNet --------------------------------------------
  * Replaces, per categorical column j, EmbeddingDrop.forward (General/Layers.py:74-76: nn.Embedding(max_norm=1.5)
  * in-place renorm + gather + per-sample dropout mask) and the two torch.cat calls of StructuredDataNet.forward

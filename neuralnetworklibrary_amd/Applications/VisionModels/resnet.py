@@ -4,7 +4,7 @@ consumed at Applications/Vision.py:1211-1212,1225-1228) built from the HIP-backe
 torchvision itself is not a dependency; if it is installed its ResNet is accepted too (Vision.default_cut)."""
 import torch.nn as nn
 
-from .retinanet import BasicBlock, Bottleneck, HipConv2d, _Downsample
+from .retinanet import BasicBlock, Bottleneck, HipConv2d, HipMaxPool2d, _Downsample
 from ... import ops
 
 __all__ = ['ResNet', 'resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152']
@@ -17,7 +17,7 @@ class ResNet(nn.Module):
         self.conv1 = HipConv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = HipMaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

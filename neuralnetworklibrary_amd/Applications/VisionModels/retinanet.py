@@ -38,6 +38,16 @@ class HipConv2d(nn.Conv2d):
         return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu)
 
 
+class HipMaxPool2d(nn.MaxPool2d):
+    "nn.MaxPool2d (floor mode, no dilation) on the NHWC HIP kernels of csrc/pool.hip (same tie rule as torch)"
+
+    def forward(self, x):
+        k, s, p = self.kernel_size, self.stride, self.padding
+        if self.dilation != 1 or self.ceil_mode or self.return_indices or not all(isinstance(v, int) for v in (k, s, p)):
+            raise NotImplementedError('HipMaxPool2d: only the square floor-mode pooling the reference uses')
+        return ops.maxpool2d(x, k, s, p)
+
+
 class _ConvReLU(HipConv2d):
     "conv followed by nn.ReLU in the reference (heads, retinanet.py:192-193 etc.): ReLU fused in the epilogue"
     fuse_relu = True
@@ -195,7 +205,7 @@ class RetinaNet(nn.Module):
         self.conv1 = HipConv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = HipMaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

@@ -120,11 +120,20 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
                                                 float (*red)[kFinLanes][2], float& s1, float& s2) {
   const int lane = threadIdx.x & (kFinLanes - 1), ch = threadIdx.x / kFinLanes;
   float a = 0.f, b = 0.f;
-  if (cok)
-    for (int p = lane; p < nparts; p += kFinLanes) {
-      a += part[((long)p * C + c) * 2 + 0];
-      b += part[((long)p * C + c) * 2 + 1];
+  if (cok) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2* pp = reinterpret_cast<const f32x2*>(part) + c;          // (S1, S2) pairs, stride C
+    int p = lane;
+    for (; p + 3 * kFinLanes < nparts; p += 4 * kFinLanes) {            // 4 independent 8-B loads in flight (the partials
+      const f32x2 v0 = pp[(long)p * C], v1 = pp[(long)(p + kFinLanes) * C];      // were written by other XCDs: each load
+      const f32x2 v2 = pp[(long)(p + 2 * kFinLanes) * C], v3 = pp[(long)(p + 3 * kFinLanes) * C];   // is a ~1 us miss)
+      a += v0[0]; b += v0[1]; a += v1[0]; b += v1[1]; a += v2[0]; b += v2[1]; a += v3[0]; b += v3[1];
     }
+    for (; p < nparts; p += kFinLanes) {
+      const f32x2 v = pp[(long)p * C];
+      a += v[0]; b += v[1];
+    }
+  }
   red[ch][lane][0] = a;
   red[ch][lane][1] = b;
   __syncthreads();

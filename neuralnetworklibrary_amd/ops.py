@@ -328,9 +328,62 @@ def bn_act(bn, x, residual=None, relu=True):
     return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt)
 
 
+class _ConcatPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_cuda(x)
+        xn = to_nhwc(x.float())
+        N, H, W, C = xn.shape
+        out = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
+        am = torch.empty(N, C, dtype=torch.int32, device=x.device)
+        check(lib.nnl_concat_pool_fwd(ptr(xn), ptr(out), ptr(am), N, H * W, C, stream()))
+        ctx.save_for_backward(am)
+        ctx.shape = (N, H, W, C)
+        return out.view(N, 2 * C, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (am,) = ctx.saved_tensors
+        N, H, W, C = ctx.shape
+        dx = torch.empty(N, H, W, C, dtype=torch.float32, device=dout.device)
+        check(lib.nnl_concat_pool_bwd(ptr(_f32c(dout.reshape(N, 2 * C))), ptr(am), ptr(dx), N, H * W, C, stream()))
+        return from_nhwc(dx)
+
+
 def concat_pool2d(x):
-    """cat([global max pool, global avg pool], 1) -> [N, 2C, 1, 1]  (AdaptiveConcatPool2d, General/Layers.py:78-87)."""
-    return torch.cat([x.amax(dim=(2, 3), keepdim=True), x.mean(dim=(2, 3), keepdim=True)], 1)
+    """cat([AdaptiveMaxPool2d(1), AdaptiveAvgPool2d(1)], 1) -> [N, 2C, 1, 1]  (AdaptiveConcatPool2d, General/Layers.py:78-87);
+    the max gradient goes to the first arg-max pixel, as torch's adaptive max pool does (pool.hip)."""
+    return _ConcatPool.apply(x)
+
+
+class _MaxPool2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ksize, stride, pad):
+        require_cuda(x)
+        xn = to_nhwc(x.float())
+        N, H, W, C = xn.shape
+        P, Q = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        y = torch.empty(N, P, Q, C, dtype=torch.float32, device=x.device)
+        idx = torch.empty(N, P, Q, C, dtype=torch.uint8, device=x.device)
+        check(lib.nnl_maxpool2d_fwd(ptr(xn), ptr(y), ptr(idx), N, H, W, C, P, Q, ksize, stride, pad, stream()))
+        ctx.save_for_backward(idx)
+        ctx.cfg = (N, H, W, C, P, Q, ksize, stride, pad)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C, P, Q, ksize, stride, pad = ctx.cfg
+        dyn = to_nhwc(dy.float())
+        dx = torch.empty(N, H, W, C, dtype=torch.float32, device=dy.device)
+        check(lib.nnl_maxpool2d_bwd(ptr(dyn), ptr(idx), ptr(dx), N, H, W, C, P, Q, ksize, stride, pad, stream()))
+        return from_nhwc(dx), None, None, None
+
+
+def maxpool2d(x, ksize=3, stride=2, pad=1):
+    """nn.MaxPool2d(ksize, stride, pad) (floor mode, no dilation) — the ResNet stem pool (retinanet.py:307,374) — NHWC,
+    channel count a multiple of 4; torch's first-maximum tie rule, deterministic gather-style backward (pool.hip)."""
+    return _MaxPool2d.apply(x, int(ksize), int(stride), int(pad))
 
 
 # ---------------------------------------------------------------------------------------------------------
