@@ -160,6 +160,24 @@ int nnl_maxpool2d_bwd(const float* dy, const uint8_t* idx, float* dx, int64_t N,
 int nnl_concat_pool_fwd(const float* x, float* out, int32_t* argmax, int64_t N, int64_t HW, int64_t C, void* stream);
 int nnl_concat_pool_bwd(const float* dout, const int32_t* argmax, float* dx, int64_t N, int64_t HW, int64_t C, void* stream);
 
+/* ---- detection inference: the device half of BBoxPredictor.__call__ / nms (Applications/VisionModels/retinanet.py:523-812)
+ * nnl_bbox_decode: per (image, anchor) best class (first maximum) and its score; keep score > thresh; decode the box
+ *   (cx + w*(reg0*std0+mean0), ..., w*exp(reg2*std2+mean2), ...), clip to [0,width]x[0,height], drop empty boxes
+ *   (retinanet.py:762-800).  anchors [A,4], reg [bs,A,4], clas [bs,A,K]; mean4 / std4 are HOST arrays.  Candidates are
+ *   appended per image in arbitrary order: cand_* have capacity A per image, cand_order = anchor index, cand_count [bs].
+ * nnl_nms: top_k candidates by (score descending, order ascending), then greedy non-maximum suppression inside a class with
+ *   IoU > max_overlap (retinanet.py:581-604; IoU in the reference's fp32 operation order).  cand_order may be NULL (= position).
+ *   kept_* [bs][top_k] in descending score order, kept_count [bs].  The remaining list filters of nms() (relative
+ *   thresholds, inclusions, cross-class duplicates, max_boxes) act on the few survivors and stay on the host. */
+int nnl_bbox_decode(const float* anchors, const float* reg, const float* clas, int64_t bs, int64_t A, int64_t K,
+                    const float* mean4, const float* std4, float thresh, float width, float height, float* cand_boxes,
+                    int32_t* cand_classes, float* cand_scores, int32_t* cand_order, int32_t* cand_count, void* stream);
+size_t nnl_nms_workspace_bytes(int64_t bs, int64_t top_k);
+int nnl_nms(const float* cand_boxes, const int32_t* cand_classes, const float* cand_scores, const int32_t* cand_order,
+            const int32_t* cand_count, int64_t bs, int64_t cap, int64_t top_k, float max_overlap, float* kept_boxes,
+            int32_t* kept_classes, float* kept_scores, int32_t* kept_count, void* workspace, size_t workspace_bytes,
+            void* stream);
+
 /* ---- K3: categorical-embedding front end of StructuredDataNet --------------------------------------------
  * Replaces, per categorical column j, EmbeddingDrop.forward (General/Layers.py:74-76: nn.Embedding(max_norm=1.5)
  * in-place renorm + gather + per-sample dropout mask) and the two torch.cat calls of StructuredDataNet.forward

@@ -192,6 +192,7 @@ class ObjectDetectionNet(nn.Module):
         self.layer_groups = [self.resnet, self.fpn, self.head]
         self.param_groups = separate_bn_layers(self.layer_groups)
         self.AnchorGenerator = R.AnchorGenerator(ratios, scales)
+        self.BBoxPredictor = R.BBoxPredictor()                    # Vision.py:1444
 
     def forward(self, x):
         """x [bs,3,H,W] -> [anchors [N,4], reg [bs,N,4], clas [bs,N,num_classes]]"""
@@ -287,6 +288,88 @@ class SSD_ClasLoss(object):
         return self.loss_func.clas_loss
 
 
+# ---- §6.3 other detection metrics (Vision.py:1666-1800) -------------------------------------------------------------------
+class ComputeMaxOverlaps(object):
+    """Mean over images of the mean over ground-truth objects of the maximum jaccard overlap with any anchor box — how well
+    the anchors cover the objects (Vision.py:1666-1694).  Also accumulates every maximum in self.max_overlaps."""
+
+    def __init__(self):
+        self.max_overlaps = []
+
+    def __call__(self, activ, target):
+        Objects, anchors, bs = target[0], activ[0], len(target[0])
+        batch_means = []
+        for i in range(bs):
+            objects = Objects[i][Objects[i] >= 0].view(-1, 4)
+            if len(objects) == 0:
+                continue
+            mx = jaccard(objects, anchors).max(dim=1)[0].detach().cpu().numpy()
+            self.max_overlaps += list(mx)
+            batch_means.append(mx.mean())
+        return TEN(np.array(batch_means).mean() if batch_means else 0.0)
+
+
+def mAP1(targs, preds, scores, thresh):
+    """Average precision of one category at one jaccard threshold over a dataset (Vision.py:1696-1747): each ground-truth box
+    marks its best-overlapping prediction correct if the overlap exceeds `thresh`; the area under the max-smoothed precision
+    curve, divided by the number of ground-truth boxes."""
+    from .VisionModels.retinanet import jaccard as np_jaccard
+    is_correct, all_scores = [], []
+    for t, p, s in zip(targs, preds, scores):
+        ok = [0] * len(p)
+        if len(p) > 0 and len(t) > 0:
+            jac = np_jaccard(np.array(t, dtype=np.float32), np.array(p, dtype=np.float32))
+            best = jac.argmax(axis=1)
+            for j, k in enumerate(best):
+                if jac[j, k] > thresh:
+                    ok[int(k)] = 1
+        is_correct += ok
+        all_scores += list(s)
+    ic = np.array([c for _, c in sorted(zip(all_scores, is_correct), reverse=True)])
+    ntrue = sum(len(t) for t in targs)
+    tp = np.cumsum(ic)
+    precision = tp * np.array([1 / n for n in range(1, len(ic) + 1)])
+    smoothed = np.flip(np.maximum.accumulate(np.flip(precision)))
+    return np.sum(smoothed[ic.nonzero()[0]]) / ntrue
+
+
+def mAP(predictions, targets, categories, thresholds=COCO_thresholds, verbose=True):
+    """Mean average precision over categories and jaccard thresholds (Vision.py:1749-1800).  predictions[i] =
+    [pred_boxes, pred_classes, conf_scores] as returned by learner.predict('val'); targets[i] = [(box, category), ...]."""
+    N, C = len(predictions), len(categories)
+    targs = [[[] for _ in range(N)] for _ in range(C)]
+    preds = [[[] for _ in range(N)] for _ in range(C)]
+    scores = [[[] for _ in range(N)] for _ in range(C)]
+    for i in range(N):
+        pred_boxes, pred_classes, conf_scores = predictions[i]
+        for j in range(len(pred_boxes)):
+            c = pred_classes[j]
+            preds[c][i].append(pred_boxes[j])
+            scores[c][i].append(conf_scores[j])
+        for b, c in targets[i]:
+            targs[c][i].append(b)
+    vals = np.zeros((len(thresholds), C))
+    for c in range(C):
+        for j, thresh in enumerate(thresholds):
+            vals[j, c] = mAP1(targs[c], preds[c], scores[c], thresh)
+            if verbose:
+                print('cat =', c, ':', categories[c], ' thresh =', thresh)
+                print('cat-thresh mAP = ', vals[j, c])
+                print('')
+    if verbose:
+        print('Overall mAP = ', np.mean(vals))
+    return np.mean(vals)
+
+
 class ImageLearner(Learner):
-    """Learner for image data (Vision.py:1803-1812): inherits fit / evaluate / predict unchanged.  The visualisation
-    and TTA conveniences of the reference's ImageLearner are UI / inference helpers (out of scope)."""
+    """Learner for image data (Vision.py:1803-1812): inherits fit / evaluate / predict unchanged, plus compute_mAP for
+    object detection.  The visualisation, TTA and pycocotools conveniences of the reference's ImageLearner are UI / external
+    tooling (out of scope)."""
+
+    def compute_mAP(self, predictions=None, thresh=0.05, max_overlap=0.5, rel_thresh=None, top_k=1000, max_boxes=20,
+                    dup=None, inc=None, mAP_thresholds=COCO_thresholds):
+        "mAP of the validation set, target_type 'bbox' only (Vision.py:2123-2140)"
+        categories, targets = self.data.categories, self.data.val_ds.y
+        if predictions is None:
+            predictions = self.predict('val', True, thresh, max_overlap, rel_thresh, top_k, max_boxes, dup, inc)
+        return mAP(predictions, targets, categories, mAP_thresholds)

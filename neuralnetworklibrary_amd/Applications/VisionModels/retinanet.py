@@ -7,7 +7,9 @@ Same classes, constructor arguments, sub-module names (=> state_dict keys) and o
   * activations flow in NHWC (channels_last) between layers;
   * `AnchorGenerator` caches the anchors per image shape ON THE DEVICE instead of rebuilding them in numpy and
     copying H2D on every forward (retinanet.py:485-495);
-  * nms / BBoxPredictor (inference post-processing, retinanet.py:500-812) are a "next" row.
+  * nms / BBoxPredictor (inference post-processing, retinanet.py:500-812): threshold + decode + clip, the top_k sort and
+    the greedy same-class NMS run in HIP kernels (csrc/detect.hip) for the whole batch at once; the list filters on the
+    few survivors (relative thresholds, inclusions, cross-class duplicates, max_boxes) are host logic as upstream.
 """
 import numpy as np
 import torch
@@ -18,7 +20,8 @@ from ...General.Core import default_device
 
 __all__ = ['HipConv2d', 'conv3x3', 'BasicBlock', 'Bottleneck', 'PyramidFeatures', 'RegressionModel',
            'ClassificationModel', 'RetinaNet', 'retinanet18', 'retinanet34', 'retinanet50', 'retinanet101',
-           'retinanet152', 'get_anchor_set', 'get_anchor_shifts', 'AnchorGenerator']
+           'retinanet152', 'get_anchor_set', 'get_anchor_shifts', 'AnchorGenerator', 'intersections', 'jaccard', 'nms',
+           'BBoxPredictor']
 
 
 class HipConv2d(nn.Conv2d):
@@ -218,6 +221,7 @@ class RetinaNet(nn.Module):
         self.regressionModel = RegressionModel(256)
         self.classificationModel = ClassificationModel(256, num_classes=num_classes)
         self.AnchorGenerator = AnchorGenerator()
+        self.BBoxPredictor = BBoxPredictor()                      # retinanet.py:325
         init_retina_modules(self.modules())
         prior = 0.01
         nn.init.constant_(self.classificationModel.output.weight, 0)
@@ -336,3 +340,157 @@ class AnchorGenerator(object):
             a = torch.as_tensor(self.numpy_anchors(key[0], key[1]), dtype=torch.float32)
             self._cache[key] = a.to(img_batch.device)
         return self._cache[key]
+
+
+# ---- BBoxPredictor and associated functions (reference retinanet.py:498-812) -------------------------------------------------
+def intersections(Boxes1, Boxes2):
+    "[n,m] intersection areas of min-max boxes given as numpy arrays (retinanet.py:500-509)"
+    B1, B2 = np.expand_dims(Boxes1, axis=1), np.expand_dims(Boxes2, axis=0)
+    inter_w = (np.minimum(B1[:, :, 2], B2[:, :, 2]) - np.maximum(B1[:, :, 0], B2[:, :, 0])).clip(0, None)
+    inter_h = (np.minimum(B1[:, :, 3], B2[:, :, 3]) - np.maximum(B1[:, :, 1], B2[:, :, 1])).clip(0, None)
+    return inter_w * inter_h
+
+
+def jaccard(Boxes1, Boxes2):
+    "[n,m] jaccard index (IoU) of min-max boxes given as numpy arrays (retinanet.py:511-521)"
+    areas1 = (Boxes1[:, 2] - Boxes1[:, 0]) * (Boxes1[:, 3] - Boxes1[:, 1])
+    areas2 = (Boxes2[:, 2] - Boxes2[:, 0]) * (Boxes2[:, 3] - Boxes2[:, 1])
+    inter = intersections(Boxes1, Boxes2)
+    return inter / (np.expand_dims(areas1, axis=1) + np.expand_dims(areas2, axis=0) - inter)
+
+
+def _device_nms(cand, bs, cap, top_k, max_overlap, device):
+    """sorted top_k + greedy same-class NMS for a batch of candidate lists on the GPU (nnl_nms); returns per image the
+    survivors as numpy arrays (boxes [m,4] f32, classes [m] i64, scores [m] f32) — ONE device->host copy for the batch."""
+    from ..._lib import check, lib, ptr, stream
+    cbox, ccls, cscore, corder, ccount = cand
+    top_k = int(min(top_k, cap))
+    kbox = torch.empty(bs, top_k, 4, dtype=torch.float32, device=device)
+    kcls = torch.empty(bs, top_k, dtype=torch.int32, device=device)
+    kscore = torch.empty(bs, top_k, dtype=torch.float32, device=device)
+    kcount = torch.empty(bs, dtype=torch.int32, device=device)
+    wsb = int(lib.nnl_nms_workspace_bytes(bs, top_k))
+    ws = torch.empty(wsb // 4 + 1, dtype=torch.float32, device=device)
+    check(lib.nnl_nms(ptr(cbox), ptr(ccls), ptr(cscore), ptr(corder), ptr(ccount), bs, cap, top_k, float(max_overlap), ptr(kbox),
+                      ptr(kcls), ptr(kscore), ptr(kcount), ptr(ws), wsb, stream()))
+    counts = kcount.cpu().numpy()
+    mx = int(counts.max()) if bs else 0
+    hb, hc, hs = kbox[:, :mx].cpu().numpy(), kcls[:, :mx].cpu().numpy().astype(np.int64), kscore[:, :mx].cpu().numpy()
+    return [(hb[i, :counts[i]], hc[i, :counts[i]], hs[i, :counts[i]]) for i in range(bs)]
+
+
+def _drop(seq, idxs):
+    idxs = set(int(i) for i in idxs)
+    return [v for i, v in enumerate(seq) if i not in idxs]
+
+
+def _prune(pred_boxes, pred_classes, conf_scores, rel_thresh, max_boxes, dup, inc):
+    """The list filters that follow the suppression loop in the reference's nms (retinanet.py:613-705), on the survivors
+    (lists sorted by descending score): relative thresholds, single inclusions of one class, cross-class duplicates,
+    max_boxes."""
+    S, C, B = list(conf_scores), list(pred_classes), list(pred_boxes)
+    if rel_thresh:
+        t1, t2 = rel_thresh
+        for i in range(len(S)):
+            if S[i] < t1 * S[0]:
+                S, C, B = S[:i], C[:i], B[:i]
+                break
+        if len(S) > 1:
+            sv, cv = np.array(S), np.array(C)
+            # j is dropped when an earlier i of its class has S[j] < t2*S[i]; with descending scores the binding i is the
+            # FIRST member of the class
+            first = {}
+            kill = []
+            for j in range(len(S)):
+                c = int(cv[j])
+                if c not in first:
+                    first[c] = j
+                elif sv[j] < t2 * sv[first[c]]:
+                    kill.append(j)
+            S, C, B = _drop(S, kill), _drop(C, kill), _drop(B, kill)
+    if inc and len(C):
+        thr, inc_classes = inc
+        L = len(C)
+        pc, pb = np.array(C), np.array(B)
+        eq = (pc[:, None] == pc[None, :]).astype(int)
+        area = (pb[:, 2] - pb[:, 0]) * (pb[:, 3] - pb[:, 1])
+        ratios = intersections(pb, pb) / area
+        ratios2 = area[None, :] / area[:, None]
+        big = ((ratios * eq > thr).astype(int) - np.identity(L, int)) * (ratios2 > 0.25).astype(int)
+        single = [int(i) for i in (big.sum(axis=1) == 1).nonzero()[0] if int(C[i]) not in inc_classes]
+        partners = {int(np.argmax(big[i])) for i in single}
+        kill = []
+        for i in set(single) - partners:
+            j = int(np.argmax(big[i]))
+            if S[i] < 0.75 * S[j]:
+                kill.append(i)
+            elif S[j] < 0.75 * S[i]:
+                kill.append(j)
+        S, C, B = _drop(S, kill), _drop(C, kill), _drop(B, kill)
+    if dup:
+        thr, pairs = dup
+        pairs = set(tuple(p) for p in pairs)
+        again = True
+        while again and len(B):
+            again = False
+            jac = jaccard(np.array(B), np.array(B))
+            L = len(B)
+            for i in range(L - 1):
+                hit = next((j for j in range(i + 1, L)
+                            if jac[i, j] > thr and (C[i], C[j]) in pairs and S[j] < 0.75 * S[i]), -1)
+                if hit >= 0:
+                    del S[hit], C[hit], B[hit]
+                    again = True
+                    break
+    return B[:max_boxes], C[:max_boxes], S[:max_boxes]
+
+
+def nms(pred_boxes, pred_classes, conf_scores, max_overlap=0.5, rel_thresh=None, top_k=1000, max_boxes=20, dup=None,
+        inc=None, print_it=False):
+    """Non-maximum suppression + box pruning for ONE image (reference retinanet.py:523-711; same arguments and outputs:
+    lists of np.array([xmin,ymin,xmax,ymax]), classes and scores in descending score order).  pred_boxes [N,4],
+    pred_classes [N], conf_scores [N] are CUDA tensors: the sort and the suppression loop run in csrc/detect.hip."""
+    if len(pred_boxes) == 0:
+        return [], [], []
+    from ..._lib import require_cuda
+    require_cuda(pred_boxes, pred_classes, conf_scores)
+    dev, N = pred_boxes.device, len(pred_boxes)
+    cand = (pred_boxes.detach().float().contiguous().view(1, N, 4), pred_classes.detach().to(torch.int32).contiguous().view(1, N),
+            conf_scores.detach().float().contiguous().view(1, N), None, torch.tensor([N], dtype=torch.int32, device=dev))
+    b, c, s = _device_nms(cand, 1, N, top_k, max_overlap, dev)[0]
+    if print_it:
+        print('after non-max-supress'); print(len(b), len(c), len(s))
+    B, C, S = _prune(list(b), list(c), list(s), rel_thresh, max_boxes, dup, inc)
+    if print_it:
+        print('after pruning / max_boxes'); print(len(B), len(C), len(S)); print('')
+    return B, C, S
+
+
+class BBoxPredictor(object):
+    """Predicted bounding boxes from RetinaNet activations, pruned by thresholding and NMS (reference retinanet.py:713-812;
+    same arguments, `mean` / `std` semantics and outputs).  The whole batch is decoded, sorted and suppressed on the GPU with
+    four kernel launches and one device->host copy of the survivors."""
+
+    def __init__(self, mean=[0., 0., 0., 0.], std=[0.1, 0.1, 0.2, 0.2]):
+        self.mean, self.std = np.asarray(mean, np.float32), np.asarray(std, np.float32)
+
+    def __call__(self, img_batch, reg, clas, anchors, thresh=0.05, max_overlap=0.5, rel_thresh=None, top_k=1000,
+                 max_boxes=20, dup=None, inc=None):
+        from ..._lib import check, lib, ptr, require_cuda, stream
+        require_cuda(reg, clas, anchors)
+        bs, _, height, width = img_batch.shape
+        reg, clas, anchors = reg.detach().float().contiguous(), clas.detach().float().contiguous(), anchors.detach().float().contiguous()
+        A, K, dev = anchors.shape[0], clas.shape[2], reg.device
+        cbox = torch.empty(bs, A, 4, dtype=torch.float32, device=dev)
+        ccls = torch.empty(bs, A, dtype=torch.int32, device=dev)
+        cscore = torch.empty(bs, A, dtype=torch.float32, device=dev)
+        corder = torch.empty(bs, A, dtype=torch.int32, device=dev)
+        ccount = torch.empty(bs, dtype=torch.int32, device=dev)
+        check(lib.nnl_bbox_decode(ptr(anchors), ptr(reg), ptr(clas), bs, A, K, self.mean.ctypes.data, self.std.ctypes.data,
+                                  float(thresh), float(width), float(height), ptr(cbox), ptr(ccls), ptr(cscore), ptr(corder),
+                                  ptr(ccount), stream()))
+        PredBoxes, PredClasses, ConfScores = [], [], []
+        for b, c, s in _device_nms((cbox, ccls, cscore, corder, ccount), bs, A, top_k, max_overlap, dev):
+            B, C, S = _prune(list(b), list(c), list(s), rel_thresh, max_boxes, dup, inc) if len(b) else ([], [], [])
+            PredBoxes.append(B); PredClasses.append(C); ConfScores.append(S)
+        return PredBoxes, PredClasses, ConfScores

@@ -53,6 +53,9 @@ SIGNATURES = {
     'nnl_maxpool2d_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_concat_pool_fwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, c_p]),
     'nnl_concat_pool_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, c_p]),
+    'nnl_bbox_decode': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, c_p, c_p, f32, f32, f32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nnl_nms_workspace_bytes': (sz, [i64, i64]),
+    'nnl_nms': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, i64, f32, c_p, c_p, c_p, c_p, c_p, sz, c_p]),
     'nnl_tab_renorm': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, f32, c_p, c_p]),
     'nnl_tab_gather_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, c_p]),
     'nnl_tab_scatter_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i32, i32, i32, i32, c_p]),

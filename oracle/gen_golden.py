@@ -479,7 +479,82 @@ def g9_host_logic():
     save('g9_host_logic', **out)
 
 
-GROUPS = {'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
+def _ragged(prefix, out, boxes, classes, scores):
+    "store one image's prediction lists as arrays"
+    out[prefix + '.boxes'] = np.array(boxes, dtype=np.float32).reshape(-1, 4)
+    out[prefix + '.classes'] = np.array(classes, dtype=np.int64).reshape(-1)
+    out[prefix + '.scores'] = np.array(scores, dtype=np.float32).reshape(-1)
+
+
+def g11_bbox_inference():
+    """G11: detection inference post-processing.  BBoxPredictor.__call__ (retinanet.py:733-812: threshold, decode, clip,
+    drop empty, nms) on synthetic activations over the 128x128 anchor set (3 images, K=4; image 2 has no candidate) for
+    four parameter sets (defaults / rel_thresh / inc+dup / small top_k); nms() alone on a hand-made cluster list; mAP1 and
+    mAP (Vision.py:1696-1800) on a small prediction / target set; ComputeMaxOverlaps (Vision.py:1666-1694)."""
+    RN = R['Applications.VisionModels.retinanet']
+    V = R['Applications.Vision']
+    out = {}
+    gen = RN.AnchorGenerator()
+    img = torch.zeros(3, 3, 128, 128)
+    anchors = gen(img)
+    Na, K = len(anchors), 4
+    rs = np.random.RandomState(31)
+    reg = torch.from_numpy((rs.standard_normal((3, Na, 4)) * 0.6).astype(np.float32))
+    logits = rs.standard_normal((3, Na, K)) * 1.6 - 2.6
+    clas = torch.from_numpy((1 / (1 + np.exp(-logits))).astype(np.float32))
+    clas[2] = 0.01                                                    # image 2: nothing above the threshold
+    out.update({'anchors': A(anchors), 'reg': A(reg), 'clas': A(clas), 'img_hw': np.array([128, 128])})
+    cases = {
+        'default': dict(thresh=0.05, max_overlap=0.5, rel_thresh=None, top_k=1000, max_boxes=20, dup=None, inc=None),
+        'rel': dict(thresh=0.3, max_overlap=0.4, rel_thresh=[0.4, 0.6], top_k=300, max_boxes=1000, dup=None, inc=None),
+        'incdup': dict(thresh=0.2, max_overlap=0.6, rel_thresh=None, top_k=1000, max_boxes=1000,
+                       dup=[0.5, [(0, 1), (1, 0), (2, 3), (3, 2)]], inc=[0.8, [1]]),
+        'topk': dict(thresh=0.05, max_overlap=0.5, rel_thresh=[0.2, 0.2], top_k=40, max_boxes=10, dup=None, inc=None),
+    }
+    pred = RN.BBoxPredictor()
+    for name, kw in cases.items():
+        PB, PC, CS = pred(img, reg, clas, anchors, **kw)
+        for i in range(3):
+            _ragged('%s.img%d' % (name, i), out, PB[i], PC[i], CS[i])
+    # nms alone: clusters of near-duplicates of 2 classes + one contained box
+    base = np.array([[10, 10, 50, 50], [12, 11, 52, 49], [11, 12, 49, 51], [60, 60, 100, 110], [61, 62, 99, 108],
+                     [10, 10, 50, 50], [20, 20, 40, 40], [15, 15, 45, 45], [70, 5, 120, 40], [72, 6, 118, 41]], np.float32)
+    cls = np.array([0, 0, 0, 1, 1, 1, 0, 0, 2, 2], np.int64)
+    sc = np.array([0.9, 0.8, 0.85, 0.7, 0.75, 0.6, 0.5, 0.95, 0.3, 0.31], np.float32)
+    out.update({'nms.in_boxes': base, 'nms.in_classes': cls, 'nms.in_scores': sc})
+    for name, kw in {'a': dict(max_overlap=0.5), 'b': dict(max_overlap=0.3, rel_thresh=[0.5, 0.9]),
+                     'c': dict(max_overlap=0.7, inc=[0.9, []], dup=[0.4, [(0, 1), (1, 0)]], max_boxes=4)}.items():
+        b, c, s_ = RN.nms(torch.from_numpy(base), torch.from_numpy(cls), torch.from_numpy(sc), **kw)
+        _ragged('nms.' + name, out, b, c, s_)
+    # mAP
+    targets = [[(np.array([10, 10, 50, 50], np.float32), 0), (np.array([60, 60, 100, 110], np.float32), 1)],
+               [(np.array([5, 5, 30, 40], np.float32), 0)],
+               []]
+    predictions = [[[np.array([11, 10, 49, 52], np.float32), np.array([58, 61, 101, 108], np.float32), np.array([0, 0, 20, 20], np.float32)],
+                    [0, 1, 0], [0.9, 0.8, 0.3]],
+                   [[np.array([6, 4, 31, 41], np.float32), np.array([5, 5, 30, 40], np.float32)], [0, 1], [0.7, 0.6]],
+                   [[np.array([1, 1, 9, 9], np.float32)], [1], [0.2]]]
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        m_all = V.mAP(predictions, targets, {0: 'a', 1: 'b'})
+        m_two = V.mAP(predictions, targets, {0: 'a', 1: 'b'}, thresholds=[0.5, 0.75])
+    out['map.coco'], out['map.two'] = np.array([m_all]), np.array([m_two])
+    targs0 = [[t[0] for t in T if t[1] == 0] for T in targets]
+    preds0 = [[b for b, c in zip(P[0], P[1]) if c == 0] for P in predictions]
+    scores0 = [[s_ for s_, c in zip(P[2], P[1]) if c == 0] for P in predictions]
+    out['map1.cat0_t50'] = np.array([V.mAP1(targs0, preds0, scores0, 0.5)])
+    # ComputeMaxOverlaps
+    objs = -torch.ones(2, 3, 4)
+    objs[0, :2] = torch.tensor([[10., 12., 60., 70.], [30., 30., 46., 62.]])
+    objs[1, :1] = torch.tensor([[0., 0., 127., 100.]])
+    cmo = V.ComputeMaxOverlaps()
+    out['cmo.objects'] = A(objs)
+    out['cmo.value'] = A(cmo([anchors, None, None], [objs, None])).reshape(1)
+    out['cmo.list'] = np.array(cmo.max_overlaps, dtype=np.float32)
+    save('g11_bbox_inference', **out)
+
+
+GROUPS = {'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)
