@@ -119,6 +119,29 @@ def retina(steps):
     run('RetinaNet R50-FPN 512x512 bs=16 K=20', learner, batches, [1e-4, 1e-3, 1e-3], 'images/s', bs, steps)
 
 
+def bbox_infer(steps):
+    """BBoxPredictor post-processing alone (decode + top_k sort + NMS + host pruning) on RetinaNet-512 sized activations."""
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import AnchorGenerator, BBoxPredictor
+    bs, K = 16, 20
+    img = torch.zeros(bs, 3, 512, 512, device=DEV)
+    anchors = AnchorGenerator()(img)
+    A = len(anchors)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    reg = torch.randn(bs, A, 4, device=DEV, generator=g) * 0.5
+    clas = torch.sigmoid(torch.randn(bs, A, K, device=DEV, generator=g) * 1.2 - 4.0)     # ~2 % of the anchors above 0.05
+    pred = BBoxPredictor()
+    for _ in range(2):
+        out = pred(img, reg, clas, anchors)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = pred(img, reg, clas, anchors)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({'config': 'BBoxPredictor bs=16, 49104 anchors x 20 classes, top_k 1000', 'ms_per_batch': round(dt * 1e3, 3),
+                      'value': round(bs / dt, 1), 'unit': 'images/s', 'boxes_img0': len(out[0][0])}))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('which', nargs='*', default=['collab', 'tabular', 'lm', 'retina'])
@@ -137,3 +160,5 @@ if __name__ == '__main__':
             lm(a.steps)
         elif w == 'retina':
             retina(a.steps)
+        elif w == 'bbox':
+            bbox_infer(max(a.steps, 10))
