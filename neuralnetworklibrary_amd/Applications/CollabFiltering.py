@@ -42,15 +42,28 @@ class CollabFilterDataset(Dataset):
 
 
 class CollabFilterDataObj(object):
-    """train / val / (test) datasets + dataloaders, target_type 'cont' (CollabFiltering.py:75-116)."""
+    """train / val / (test) datasets + dataloaders, target_type 'cont' (CollabFiltering.py:75-116).
+    device_resident=True (MI355X addition): the id / rating arrays live in HBM and minibatches are
+    gathered on the device (device_data.DeviceBatches) instead of going through DataLoader workers and per-step H2D copies;
+    under torch.distributed every rank takes its slice of each global minibatch."""
 
     def __init__(self, train_df, val_df, user_col, item_col, rating_col,
-                 labels, bs, num_workers=6, test_df=None):
+                 labels, bs, num_workers=6, test_df=None, device_resident=False, seed=0):
         self.bs, self.labels, self.target_type = bs, labels, 'cont'
         self.train_ds = CollabFilterDataset(train_df, user_col, item_col, rating_col, labels)
         self.val_ds = CollabFilterDataset(val_df, user_col, item_col, rating_col, labels)
         if test_df is not None:
             self.test_ds = CollabFilterDataset(test_df, user_col, item_col, None, labels)
+        if device_resident:
+            from .. import dist as nnl_dist
+            from ..device_data import DeviceBatches
+            mk = lambda ds, shuffle, shard: DeviceBatches(
+                ds.x, ds.y, bs, shuffle=shuffle, seed=seed, rank=nnl_dist.rank() if shard else 0,
+                world=nnl_dist.world_size() if shard else 1)
+            self.train_dl, self.val_dl = mk(self.train_ds, True, True), mk(self.val_ds, False, False)
+            if test_df is not None:
+                self.test_dl = mk(self.test_ds, False, False)
+            return
         kw = dict(batch_size=bs, num_workers=num_workers, pin_memory=True)
         self.train_dl = DataLoader(self.train_ds, shuffle=True, **kw)
         self.val_dl = DataLoader(self.val_ds, shuffle=False, **kw)

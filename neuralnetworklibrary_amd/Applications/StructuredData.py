@@ -60,12 +60,28 @@ def StructuredDataCollater(batch):
 
 
 class StructuredDataObj(object):
-    "train / val / (test) StructuredDatasets + dataloaders (StructuredData.py:871-911)"
+    """train / val / (test) StructuredDatasets + dataloaders (StructuredData.py:871-911).
+    device_resident=True (MI355X addition): x_cat / x_cont / y live in HBM and `[xcat, xcont], y`
+    minibatches are gathered on the device (device_data.DeviceBatches): no DataLoader workers, collate or per-step H2D."""
 
-    def __init__(self, train_ds, val_ds, category_labels, scaling_values, bs, num_workers=6, test_ds=None):
+    def __init__(self, train_ds, val_ds, category_labels, scaling_values, bs, num_workers=6, test_ds=None,
+                 device_resident=False, seed=0):
         self.train_ds, self.val_ds, self.test_ds = train_ds, val_ds, test_ds
         self.category_labels, self.scaling_values = category_labels, scaling_values
         self.bs, self.num_workers, self.target_type = bs, num_workers, train_ds.target_type
+        if device_resident:
+            from .. import dist as nnl_dist
+            from ..device_data import DeviceBatches
+            def mk(ds, shuffle, shard):
+                y = np.asarray(ds.y)
+                y = y.astype('int64') if ds.target_type == 'cat' else y.astype('float32')
+                return DeviceBatches([np.asarray(ds.x_cat).astype('int64'), np.asarray(ds.x_cont).astype('float32')], y, bs,
+                                     shuffle=shuffle, seed=seed, rank=nnl_dist.rank() if shard else 0,
+                                     world=nnl_dist.world_size() if shard else 1)
+            self.train_dl, self.val_dl = mk(train_ds, True, True), mk(val_ds, False, False)
+            if self.test_ds:
+                self.test_dl = mk(test_ds, False, False)
+            return
         kw = dict(batch_size=bs, collate_fn=StructuredDataCollater, num_workers=num_workers, pin_memory=True)
         self.train_dl = DataLoader(train_ds, shuffle=True, **kw)
         self.val_dl = DataLoader(val_ds, shuffle=False, **kw)

@@ -32,10 +32,12 @@ from .. import ops
 class LanguageModelDataLoader(object):
     """All texts concatenated, split into bs parallel streams [bs, seqlen+1]; yields consecutive (x, y) windows of
     `bptt` tokens (train: 5 % of batches halved, minus U{0..9} jitter), y = x shifted by one (Text.py:231-290).
-    `ds` needs `.texts` (sequence of token-id lists, or a pandas Series) and `.num_tokens`."""
+    `ds` needs `.texts` (sequence of token-id lists, or a pandas Series) and `.num_tokens`.
+    device_resident=True (MI355X addition): the `[bs, seqlen+1]` token matrix is uploaded once per epoch
+    and the (x, y) windows are device slices — no per-step numpy -> tensor -> H2D copy."""
 
-    def __init__(self, ds, bs, bptt, random=True):
-        self.bs, self.bptt, self.random = bs, bptt, random
+    def __init__(self, ds, bs, bptt, random=True, device_resident=False):
+        self.bs, self.bptt, self.random, self.device_resident = bs, bptt, random, device_resident
         self.texts, self.ntexts = ds.texts, len(ds.texts)
         self.seqlen = (ds.num_tokens // bs) - 1
         self.ntoks = bs * (self.seqlen + 1)
@@ -51,6 +53,7 @@ class LanguageModelDataLoader(object):
             np.random.shuffle(idxs)
         flat = np.concatenate([np.asarray(self._text(i), dtype=np.int64) for i in idxs])[:self.ntoks]
         self.combined_text = flat.reshape(self.bs, self.seqlen + 1)
+        self.combined_dev = TEN(self.combined_text) if self.device_resident else None
 
     def set_batch_lengths(self):
         self.batch_lengths = []
@@ -72,7 +75,10 @@ class LanguageModelDataLoader(object):
     def __iter__(self):
         used = 0
         for bl in self.batch_lengths:
-            yield (TEN(self.combined_text[:, used:used + bl]), TEN(self.combined_text[:, used + 1:used + bl + 1]))
+            if self.combined_dev is not None:
+                yield (self.combined_dev[:, used:used + bl].contiguous(), self.combined_dev[:, used + 1:used + bl + 1].contiguous())
+            else:
+                yield (TEN(self.combined_text[:, used:used + bl]), TEN(self.combined_text[:, used + 1:used + bl + 1]))
             used += bl
         if self.random:
             self.concat_texts()
@@ -81,13 +87,13 @@ class LanguageModelDataLoader(object):
 class LanguageModelDataObj(object):
     "train / val / (test) LanguageModelDataLoaders, target_type 'lang_model' (Text.py:292-304)"
 
-    def __init__(self, train_ds, val_ds, test_ds, bs, bptt):
+    def __init__(self, train_ds, val_ds, test_ds, bs, bptt, device_resident=False):
         self.bs, self.bptt, self.stoi, self.target_type = bs, bptt, train_ds.stoi, 'lang_model'
         self.train_ds, self.val_ds, self.test_ds = train_ds, val_ds, test_ds
-        self.train_dl = LanguageModelDataLoader(train_ds, bs, bptt, True)
-        self.val_dl = LanguageModelDataLoader(val_ds, bs, bptt, False)
+        self.train_dl = LanguageModelDataLoader(train_ds, bs, bptt, True, device_resident)
+        self.val_dl = LanguageModelDataLoader(val_ds, bs, bptt, False, device_resident)
         if test_ds:
-            self.test_dl = LanguageModelDataLoader(test_ds, bs, bptt, False)
+            self.test_dl = LanguageModelDataLoader(test_ds, bs, bptt, False, device_resident)
 
 
 # ---- models --------------------------------------------------------------------------------------------------------
