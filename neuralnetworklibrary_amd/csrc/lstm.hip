@@ -3,7 +3,7 @@
 //
 // The time loop lives HERE (one C call per layer per direction, no Python per-step overhead).  Each timestep is
 //   (1) one skinny fp32-MFMA GEMM  h_{t-1} [B,H] x W_hh^T  (fwd)  /  dgates_t [B,4H] x W_hh  (bwd), launched with SPLIT-K
-//       so that the 64x64 output tiles x k-ranges give ~288 workgroups (the plain tile grid would occupy 18-72 of the 256
+//       so that the 64x64 output tiles x k-ranges give <= 256 workgroups (the plain tile grid would occupy 18-72 of the 256
 //       CUs); every split writes its own fp32 slab;
 //   (2) one fused pointwise cell kernel that ALSO performs the fixed-order slab reduction (and adds the input projection
 //       gx_t), so split-K costs no extra launch and stays bitwise reproducible.
@@ -96,10 +96,14 @@ int ew_grid(long n) {
 
 long ceil32(long x) { return nnl_cdiv(x, 32) * 32; }
 
-// split count that brings the workgroup count of an [M x N] output (64x64 tiles) with nk k-tiles to ~288
+// split count that brings the workgroup count of an [M x N] output (64x64 tiles) with nk k-tiles close to, but not above,
+// the 256 CUs: one workgroup per CU is MFMA-bound inside its 4 waves, so a 257th workgroup doubles the step time
+// (measured: 288 workgroups 10.8 ms/step of LSTM time, 216-250: 9.7 ms, 576: 11.4 ms)
 int pick_splits(long M, long N, long nk) {
   const long tiles = nnl_cdiv(M, 64) * nnl_cdiv(N, 64);
-  long s = (288 + tiles / 2) / tiles;
+  const char* e = getenv("NNL_LSTM_WG");                     // tuning hook: workgroup budget
+  const long target = e ? atol(e) : 256;
+  long s = target / tiles;
   if (s < 1) s = 1;
   if (s > nk) s = nk;
   if (s > 32) s = 32;
