@@ -91,8 +91,11 @@ int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
 int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
 /* dx[N,H,W,C] = sum_{r,s,k} dy[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * wt[c,r,s,k] (integral taps only). */
 size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g);   /* optional workspace, as for the forward */
-int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* workspace,
-                     size_t workspace_bytes, void* stream);
+/* addend (optional, [N,H,W,C], stride 1 and K % 16 == 0 only): dx = dgrad + addend — the gradient that reaches the block
+ * input through the identity shortcut of BasicBlock / Bottleneck (retinanet.py:43-59) is added in the epilogue instead of
+ * by a separate autograd accumulation kernel. */
+int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
  * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */
 size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g);

@@ -34,11 +34,11 @@ class HipConv2d(nn.Conv2d):
         super().__init__(*args, **kwargs)
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x):
+    def forward(self, x, grad_slot=None):
         if self.dilation != (1, 1) or self.groups != 1 or self.stride[0] != self.stride[1] \
                 or self.padding[0] != self.padding[1] or self.padding_mode != 'zeros':
             raise NotImplementedError('HipConv2d: only the symmetric, dense convolutions the reference uses')
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu)
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu, grad_slot=grad_slot)
 
 
 class HipMaxPool2d(nn.MaxPool2d):
@@ -76,9 +76,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = ops.bn_act(self.bn1, self.conv1(x), relu=True)
+        # identity shortcut: its gradient is added inside conv1's dgrad kernel (ops.GradSlot) instead of by autograd
+        slot = ops.GradSlot() if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        out = ops.bn_act(self.bn1, self.conv1(x, grad_slot=slot), relu=True)
         residual = x if self.downsample is None else self.downsample(x)
-        return ops.bn_act(self.bn2, self.conv2(out), residual=residual, relu=True)
+        return ops.bn_act(self.bn2, self.conv2(out), residual=residual, relu=True, grad_slot=slot)
 
 
 class Bottleneck(nn.Module):
@@ -98,10 +100,11 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = ops.bn_act(self.bn1, self.conv1(x), relu=True)
+        slot = ops.GradSlot() if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        out = ops.bn_act(self.bn1, self.conv1(x, grad_slot=slot), relu=True)
         out = ops.bn_act(self.bn2, self.conv2(out), relu=True)
         residual = x if self.downsample is None else self.downsample(x)
-        return ops.bn_act(self.bn3, self.conv3(out), residual=residual, relu=True)
+        return ops.bn_act(self.bn3, self.conv3(out), residual=residual, relu=True, grad_slot=slot)
 
 
 class _Downsample(nn.Sequential):

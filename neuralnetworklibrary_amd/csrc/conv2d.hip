@@ -278,12 +278,24 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols, int nchunk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols,
+                                                            int nchunk) {
+  // 256 threads = 16 columns x 16 chunk lanes: lane l adds chunks l, l+16, ... (independent loads), then the 16 partial
+  // sums of a column are added in lane order through LDS (fixed order => reproducible)
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float acc = 0.f;
-  for (int k = 0; k < nchunk; ++k) acc += part[(long)k * cols + c];
-  out[c] = acc;
+  if (c < cols)
+    for (int k = kl; k < nchunk; k += 16) acc += part[(long)k * cols + c];
+  red[kl][cl] = acc;
+  __syncthreads();
+  if (kl == 0 && c < cols) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) t += red[l][cl];
+    out[c] = t;
+  }
 }
 
 int colsum_chunks(long rows) {
@@ -487,12 +499,17 @@ extern "C" int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int
   return NNL_OK;
 }
 
-extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   int st = check_geom(g, "conv2d_dgrad");
   if (st) return st;
   NNL_CHECK_ARG(dy && wt && dx, "conv2d_dgrad: null pointer");
   NNL_CHECK_ARG(g->K % 4 == 0, "conv2d_dgrad: K=%d must be a multiple of 4", g->K);
+  {
+    const bool taps = taps_ok((long)g->N * g->P * g->Q * g->K, (long)g->C * g->R * g->S * g->K, g->K, g->R * g->S);
+    if (addend != nullptr && !(taps && g->stride == 1))
+      return nnl_set_error(NNL_ERR_UNSUPPORTED, "conv2d_dgrad: the fused addend needs stride 1 and K %% 16 == 0");
+  }
   hipStream_t s = (hipStream_t)stream;
   IgemmRowkParams p{};
   p.a = dy; p.b = wt; p.y = dx; p.bias = nullptr;
@@ -504,7 +521,7 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
   const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
   if (taps_ok(a_elems, b_elems, g->K, g->R * g->S) && (g->stride == 1 || g->stride == 2)) {
     IgemmTapsParams q{};
-    q.a = dy; q.b = wt; q.y = dx; q.bias = nullptr; q.add = nullptr;
+    q.a = dy; q.b = wt; q.y = dx; q.bias = nullptr; q.add = addend;
     q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
     q.H = g->P; q.W = g->Q; q.C = g->K;                     // gathered tensor = dy [N][P][Q][K]
     q.in_stride = 1; q.ih0 = 0; q.iw0 = 0;
@@ -610,7 +627,7 @@ extern "C" int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nnl_cdiv(cols, 64), nchunk), dim3(256), 0, s, a, (float*)workspace,
                      (long)rows, (int)cols, rpc);
   NNL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nnl_cdiv(cols, 256)), dim3(256), 0, s, (const float*)workspace, out, (int)cols,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nnl_cdiv(cols, 16)), dim3(256), 0, s, (const float*)workspace, out, (int)cols,
                      nchunk);
   NNL_CHECK_LAUNCH();
   return NNL_OK;

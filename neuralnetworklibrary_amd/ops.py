@@ -106,13 +106,26 @@ def _pad_c4(t_nhwc):
     return torch.nn.functional.pad(t_nhwc, (0, 4 - C % 4))
 
 
+class GradSlot:
+    """Side channel between two autograd Functions of one residual block: the BN that closes the block parks the gradient of
+    its identity shortcut here (instead of returning it to autograd) and the block's FIRST convolution adds it in the
+    epilogue of its dgrad kernel — one accumulation kernel and three tensor passes less per block.  Valid because the first
+    convolution's backward always runs after the closing BN's backward (it depends on it through the main path) and both
+    consume the same tensor x."""
+    __slots__ = ('tensor',)
+
+    def __init__(self):
+        self.tensor = None
+
+
 class _Conv2d(torch.autograd.Function):
     """nn.Conv2d forward/backward (reference Applications/VisionModels/retinanet.py:26-28,66-71,106-124,169-185,
     241-257,304,345) on the fp32-MFMA implicit-GEMM kernels; optional fused bias + ReLU epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu):
+    def forward(ctx, x, weight, bias, stride, pad, relu, slot=None):
         require_cuda(x, weight, bias)
+        ctx.slot = slot
         xn = _pad_c4(to_nhwc(_f32c(x) if x.dim() != 4 else x.float()))
         wn = _pad_c4(to_nhwc(weight.float()))
         N, H, W, C = xn.shape
@@ -147,8 +160,16 @@ class _Conv2d(torch.autograd.Function):
             dxn = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyn.device)
             wsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g))
             dws = torch.empty(wsb // 4, dtype=torch.float32, device=dyn.device) if wsb else None
-            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(dws), wsb, stream()))
+            shortcut = None
+            if ctx.slot is not None:
+                shortcut, ctx.slot.tensor = ctx.slot.tensor, None
+            fuse = shortcut is not None and g.stride == 1 and g.K % 16 == 0 and shortcut.numel() == dxn.numel()
+            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb, stream()))
+            if shortcut is not None and not fuse:
+                dxn += shortcut.view_as(dxn)
             dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
+        elif ctx.slot is not None:
+            ctx.slot.tensor = None
         if ctx.needs_input_grad[1]:
             dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
             ws_bytes = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
@@ -161,12 +182,13 @@ class _Conv2d(torch.autograd.Function):
             cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device)
             check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, ptr(cws), cb, stream()))
             db = db_full[:K]
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False):
-    """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S]."""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu))
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, grad_slot=None):
+    """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S].
+    grad_slot: see GradSlot (the shortcut gradient of a residual block, added to dx inside the dgrad kernel)."""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu), grad_slot)
 
 
 def linear(x, weight, bias=None, relu=False):
@@ -196,8 +218,9 @@ def _rows_view(x):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt, slot=None):
         require_cuda(x, residual, gamma, beta)
+        ctx.slot = slot
         xm, back = _rows_view(x)
         rows, C = xm.shape
         rm = None if residual is None else _rows_view(residual)[0]
@@ -227,7 +250,9 @@ class _BNAct(torch.autograd.Function):
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
         check(lib.nnl_bn_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
                              ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
-        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 7
+        if ctx.slot is not None and dres is not None:
+            ctx.slot.tensor, dres = dres, None              # the block's first conv adds it to its dx (GradSlot)
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 8
 
 
 def _sync_group_size(group):
@@ -241,8 +266,9 @@ class _SyncBNAct(torch.autograd.Function):
     torch.distributed process group (None = WORLD); gather_fn / reduce_fn are injectable for single-process tests."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, nbt, group, comm):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, momentum, eps, relu, nbt, group, comm, slot=None):
         require_cuda(x, residual, gamma, beta)
+        ctx.slot = slot
         xm, back = _rows_view(x)
         rows, C = xm.shape
         rm = None if residual is None else _rows_view(residual)[0]
@@ -283,7 +309,9 @@ class _SyncBNAct(torch.autograd.Function):
         check(lib.nnl_bn_sync_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(sums), ptr(total),
                                   ptr(all_stats), int(all_stats.shape[0]), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), rows, C,
                                   int(relu), ptr(ws), wsb, stream()))
-        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 8
+        if ctx.slot is not None and dres is not None:
+            ctx.slot.tensor, dres = dres, None
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 9
 
 
 class DistComm:
@@ -305,7 +333,7 @@ class DistComm:
         return out
 
 
-def bn_act(bn, x, residual=None, relu=True):
+def bn_act(bn, x, residual=None, relu=True, grad_slot=None):
     """BatchNorm (train: batch statistics + running-stat update; eval: running stats) -> (+ residual) -> ReLU in the HIP
     kernels of batchnorm.hip: the bn -> `out += residual` -> relu tail of BasicBlock / Bottleneck (reference
     retinanet.py:47-48,53-57,81-95), the stem (:372-373) and the BatchNorm1d layers (General/Layers.py:40).
@@ -324,8 +352,9 @@ def bn_act(bn, x, residual=None, relu=True):
     rvar = bn.running_var if (not training or bn.track_running_stats) else None
     sync = getattr(bn, 'nnl_sync', None)
     if sync is not None and training:
-        return _SyncBNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, momentum, bn.eps, relu, nbt, sync[0], sync[1])
-    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt)
+        return _SyncBNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, momentum, bn.eps, relu, nbt, sync[0], sync[1],
+                                grad_slot)
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt, grad_slot)
 
 
 class _ConcatPool(torch.autograd.Function):

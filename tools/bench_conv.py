@@ -57,7 +57,7 @@ def ab(args):
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
         fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, stream())),
-               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, ptr(dws), dwsb, stream())),
+               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, stream())),
                'wgrad': lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), ws.numel() * 4, stream()))}
         for pname, fn in fns.items():
             if name == 'stem7x7' and pname == 'dgrad':
@@ -102,7 +102,7 @@ def main():
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
         t_f = timeit(lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, stream())))
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
-        t_d = timeit(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, ptr(dws), dwsb, stream())))
+        t_d = timeit(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, stream())))
         t_w = timeit(lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), wsb, stream())))
         print('%-10s %9.2f | %8.3f %7.1f | %8.3f %7.1f | %8.3f %7.1f' % (
             name, flop / 1e9, t_f, flop / t_f / 1e9, t_d, flop / t_d / 1e9, t_w, flop / t_w / 1e9))

@@ -30,7 +30,7 @@ for _ in range(a.iters):
     if a.which == 'fwd':
         check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, stream()))
     elif a.which == 'dgrad':
-        check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, ptr(dws), dwsb, stream()))
+        check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, stream()))
     else:
         check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), wsb, stream()))
 torch.cuda.synchronize()
