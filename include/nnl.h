@@ -114,17 +114,20 @@ int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* wor
  *   running = (1-momentum)*running + momentum*batch   (running_* may be NULL: track_running_stats=False);
  * training==0: normalise with running_mean / running_var.
  * y = (x-mean)*invstd*gamma + beta [+ residual] [ReLU].  save_mean/save_invstd [C] are kept for backward.
- * num_batches_tracked (device int64, may be NULL): nn.BatchNorm's step counter, incremented by the training call. */
+ * num_batches_tracked (device int64, may be NULL): nn.BatchNorm's step counter, incremented by the training call.
+ * relu_mask (optional, with relu != 0): ceil(rows*C/32) + 2 words; bit e of the flat [rows, C] element index is set when
+ * y > 0.  Pass it to the backward instead of y: the ReLU gate then costs 1 bit instead of 32 per element of HBM traffic. */
 size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C);
 int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
                int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
-               void* workspace, size_t workspace_bytes, void* stream);
-/* g = dy * [y > 0] (if relu);  dbeta = sum g;  dgamma = sum g*xhat;  dres = g (if dres != NULL);
+               uint32_t* relu_mask, void* workspace, size_t workspace_bytes, void* stream);
+/* g = dy * [y > 0] (if relu; the gate comes from relu_mask when given, else from y);  dbeta = sum g;  dgamma = sum g*xhat;
+ * dres = g (if dres != NULL);
  * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) (training) or gamma*invstd*g (eval). dgamma/dbeta may be NULL. */
-int nnl_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
-               const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C,
-               int training, int relu, void* workspace, size_t workspace_bytes, void* stream);
+int nnl_bn_bwd(const float* dy, const float* y, const uint32_t* relu_mask, const float* x, const float* gamma,
+               const float* mean, const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows,
+               int64_t C, int training, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Cross-replica (synchronised) training-mode BatchNorm for data parallelism (global-batch statistics equal
  * to the single-GPU reference's).  Split-phase, the host runs the collective in between (neuralnetworklibrary_amd/ops.py):
@@ -139,12 +142,13 @@ int nnl_bn_sync_stats(const float* x, float* stats, int64_t rows, int64_t C, voi
 int nnl_bn_sync_fwd(const float* x, const float* all_stats, int world, const float* gamma, const float* beta,
                     const float* residual, float* y, float* save_mean, float* save_invstd, float* running_mean,
                     float* running_var, int64_t rows, int64_t C, float eps, float momentum, int relu,
-                    int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream);
-int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                           float* sums, int64_t rows, int64_t C, int relu, void* workspace, size_t workspace_bytes,
-                           void* stream);
-int nnl_bn_sync_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
-                    const float* invstd, const float* local_sums, const float* global_sums, const float* all_stats,
+                    int64_t* num_batches_tracked, uint32_t* relu_mask, void* workspace, size_t workspace_bytes, void* stream);
+int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const uint32_t* relu_mask, const float* x, const float* mean,
+                           const float* invstd, float* sums, int64_t rows, int64_t C, int relu, void* workspace,
+                           size_t workspace_bytes, void* stream);
+int nnl_bn_sync_bwd(const float* dy, const float* y, const uint32_t* relu_mask, const float* x, const float* gamma,
+                    const float* mean, const float* invstd, const float* local_sums, const float* global_sums,
+                    const float* all_stats,
                     int world, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C, int relu,
                     void* workspace, size_t workspace_bytes, void* stream);
 

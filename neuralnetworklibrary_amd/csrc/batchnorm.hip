@@ -248,33 +248,63 @@ __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const floa
 }
 
 // ---- apply: y = x*scale + shift (+ residual) (ReLU) ---------------------------------------------------------------
+// ReLU keep-bits: bit (i*VEC + e) of the mask says whether element e of vector i was positive after the ReLU.  The backward
+// kernels read the mask (1 bit per element) instead of re-reading y (32 bits per element).
+template <int VEC>
+__device__ __forceinline__ unsigned keep_bits(const unsigned* __restrict__ mask, long i) {
+  const long bit = i * VEC;
+  return (mask[bit >> 5] >> (bit & 31)) & ((1u << VEC) - 1u);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kBlock) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                            const float* __restrict__ shift,
                                                            const float* __restrict__ residual, float* __restrict__ y,
-                                                           long total_v, int CG, int relu) {
+                                                           long total_v, int CG, int relu, unsigned* __restrict__ mask) {
   typedef typename VecT<VEC>::type V;
-  const long stride = (long)gridDim.x * blockDim.x;          // host guarantees stride % CG == 0
+  const long stride = (long)gridDim.x * blockDim.x;          // host guarantees stride % CG == 0 (and stride % 256 == 0)
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = (int)((unsigned)i0 % (unsigned)CG);
+  const int lane = threadIdx.x & 63;
+  const int g = (int)((unsigned long)i0 % (unsigned)CG);
   const V sc = reinterpret_cast<const V*>(scale)[g];
   const V sh = reinterpret_cast<const V*>(shift)[g];
-  for (long i = i0; i < total_v; i += stride) {
-    const V xv = reinterpret_cast<const V*>(x)[i];
-    V out;
-    if (residual) {
-      const V rv = reinterpret_cast<const V*>(residual)[i];
+  for (long base = i0 - lane; base < total_v; base += stride) {      // wave-uniform trip count (the mask is packed by shuffles)
+    const long i = base + lane;
+    const bool ok = i < total_v;
+    unsigned bits = 0;
+    if (ok) {
+      const V xv = reinterpret_cast<const V*>(x)[i];
+      V out;
+      if (residual) {
+        const V rv = reinterpret_cast<const V*>(residual)[i];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, vget<VEC>(xv, e) * vget<VEC>(sc, e) + vget<VEC>(sh, e) + vget<VEC>(rv, e));
-    } else {
+        for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, vget<VEC>(xv, e) * vget<VEC>(sc, e) + vget<VEC>(sh, e) + vget<VEC>(rv, e));
+      } else {
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, vget<VEC>(xv, e) * vget<VEC>(sc, e) + vget<VEC>(sh, e));
+        for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, vget<VEC>(xv, e) * vget<VEC>(sc, e) + vget<VEC>(sh, e));
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (vget<VEC>(out, e) > 0.f) bits |= 1u << e;
+          vset<VEC>(out, e, fmaxf(vget<VEC>(out, e), 0.f));
+        }
+      }
+      reinterpret_cast<V*>(y)[i] = out;
     }
-    if (relu) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) vset<VEC>(out, e, fmaxf(vget<VEC>(out, e), 0.f));
+    if (mask != nullptr) {
+      if (VEC == 4) {                                        // 8 lanes x 4 bits -> one word
+        unsigned w = bits << ((lane & 7) * 4);
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        w |= __shfl_xor(w, 4, 64);
+        if ((lane & 7) == 0 && ok) mask[i >> 3] = w;
+      } else {                                               // 64 lanes x 1 bit -> two words
+        const unsigned long long b = __ballot(bits & 1u);
+        if (lane == 0 && ok) mask[base >> 5] = (unsigned)b;
+        if (lane == 32 && ok) mask[(base >> 5) + 1] = (unsigned)(b >> 32);
+      }
     }
-    reinterpret_cast<V*>(y)[i] = out;
   }
 }
 
@@ -283,7 +313,8 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                 const float* __restrict__ x, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, float* __restrict__ part,
-                                                                long rows, int C, int L, int relu) {
+                                                                long rows, int C, int L, int relu,
+                                                                const unsigned* __restrict__ mask) {
   typedef typename VecT<VEC>::type V;
   __shared__ float red[kBlock * 2 * VEC];
   const int CG = C / VEC;
@@ -301,20 +332,24 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __re
     long r = (long)blockIdx.x * rpb + ty;
     for (; r + rstep < rows; r += 2 * rstep) {              // 2 x 3 independent 16-B loads in flight per lane
       V dv[2], xv[2], yv[2];
+      unsigned kb[2] = {~0u, ~0u};
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const long off = (r + u * rstep) * C + (long)g * VEC;
         dv[u] = *reinterpret_cast<const V*>(dy + off);
         xv[u] = *reinterpret_cast<const V*>(x + off);
         yv[u] = dv[u];
-        if (relu) yv[u] = *reinterpret_cast<const V*>(y + off);
+        if (relu) {
+          if (mask) kb[u] = keep_bits<VEC>(mask, off / VEC);
+          else yv[u] = *reinterpret_cast<const V*>(y + off);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float gg = vget<VEC>(dv[u], e);
-          if (relu && !(vget<VEC>(yv[u], e) > 0.f)) gg = 0.f;
+          if (relu && (mask ? !((kb[u] >> e) & 1u) : !(vget<VEC>(yv[u], e) > 0.f))) gg = 0.f;
           s1[e] += gg;
           s2[e] += gg * ((vget<VEC>(xv[u], e) - mu[e]) * is[e]);
         }
@@ -324,11 +359,15 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_reduce_kernel(const float* __re
       const V dv = *reinterpret_cast<const V*>(dy + off);
       const V xv = *reinterpret_cast<const V*>(x + off);
       V yv = dv;
-      if (relu) yv = *reinterpret_cast<const V*>(y + off);
+      unsigned kb = ~0u;
+      if (relu) {
+        if (mask) kb = keep_bits<VEC>(mask, off / VEC);
+        else yv = *reinterpret_cast<const V*>(y + off);
+      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         float gg = vget<VEC>(dv, e);
-        if (relu && !(vget<VEC>(yv, e) > 0.f)) gg = 0.f;
+        if (relu && (mask ? !((kb >> e) & 1u) : !(vget<VEC>(yv, e) > 0.f))) gg = 0.f;
         s1[e] += gg;
         s2[e] += gg * ((vget<VEC>(xv, e) - mu[e]) * is[e]);
       }
@@ -420,7 +459,8 @@ template <int VEC>
 __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                                const float* __restrict__ x, const float* __restrict__ coef,
                                                                float* __restrict__ dx, float* __restrict__ dres,
-                                                               long total_v, int CG, int C, int relu) {
+                                                               long total_v, int CG, int C, int relu,
+                                                               const unsigned* __restrict__ mask) {
   typedef typename VecT<VEC>::type V;
   const long stride = (long)gridDim.x * blockDim.x;          // host guarantees stride % CG == 0
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -433,10 +473,17 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_apply_kernel(const float* __res
     const V xv = reinterpret_cast<const V*>(x)[i];
     V gv = dv;
     if (relu) {
-      const V yv = reinterpret_cast<const V*>(y)[i];
+      if (mask) {
+        const unsigned kb = keep_bits<VEC>(mask, i);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        if (!(vget<VEC>(yv, e) > 0.f)) vset<VEC>(gv, e, 0.f);
+        for (int e = 0; e < VEC; ++e)
+          if (!((kb >> e) & 1u)) vset<VEC>(gv, e, 0.f);
+      } else {
+        const V yv = reinterpret_cast<const V*>(y)[i];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (!(vget<VEC>(yv, e) > 0.f)) vset<VEC>(gv, e, 0.f);
+      }
     }
     V out;
 #pragma unroll
@@ -471,7 +518,7 @@ extern "C" size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C) {
 extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                           float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
                           int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          uint32_t* relu_mask, void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_fwd: bad sizes rows=%ld C=%ld", (long)rows, (long)C);
   NNL_CHECK_ARG(x && y && save_mean && save_invstd, "bn_fwd: null pointer");
   NNL_CHECK_ARG(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
@@ -504,19 +551,20 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
   const long total_v = rows * CG;
   if (VEC == 4)
     hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
-                       (int)CG, relu);
+                       (int)CG, relu, relu ? relu_mask : nullptr);
   else
     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
-                       (int)CG, relu);
+                       (int)CG, relu, relu ? relu_mask : nullptr);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
 
-extern "C" int nnl_bn_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
-                          const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows,
-                          int64_t C, int training, int relu, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int nnl_bn_bwd(const float* dy, const float* y, const uint32_t* relu_mask, const float* x, const float* gamma,
+                          const float* mean, const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta,
+                          int64_t rows, int64_t C, int training, int relu, void* workspace, size_t workspace_bytes,
+                          void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_bwd: bad sizes");
-  NNL_CHECK_ARG(dy && x && mean && invstd && dx && (y || !relu), "bn_bwd: null pointer");
+  NNL_CHECK_ARG(dy && x && mean && invstd && dx && (y || relu_mask || !relu), "bn_bwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
     return nnl_set_error(NNL_ERR_WORKSPACE, "bn_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -528,10 +576,10 @@ extern "C" int nnl_bn_bwd(const float* dy, const float* y, const float* x, const
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (relu ? 28.0 : 20.0) + (dres ? 4.0 * rows * C : 0.0));
   if (VEC == 4)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
-                       (int)C, sh.L, relu);
+                       (int)C, sh.L, relu, relu_mask);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
-                       (int)C, sh.L, relu);
+                       (int)C, sh.L, relu, relu_mask);
   NNL_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, part, sh.gx, gamma, mean, invstd,
                      dgamma, dbeta, coef, (long)rows, (int)C, training);
@@ -539,10 +587,10 @@ extern "C" int nnl_bn_bwd(const float* dy, const float* y, const float* x, const
   const long total_v = rows * CG;
   if (VEC == 4)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
-                       (int)CG, (int)C, relu);
+                       (int)CG, (int)C, relu, relu_mask);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
-                       (int)CG, (int)C, relu);
+                       (int)CG, (int)C, relu, relu_mask);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -580,7 +628,8 @@ extern "C" int nnl_bn_sync_stats(const float* x, float* stats, int64_t rows, int
 extern "C" int nnl_bn_sync_fwd(const float* x, const float* all_stats, int world, const float* gamma, const float* beta,
                                const float* residual, float* y, float* save_mean, float* save_invstd, float* running_mean,
                                float* running_var, int64_t rows, int64_t C, float eps, float momentum, int relu,
-                               int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream) {
+                               int64_t* num_batches_tracked, uint32_t* relu_mask, void* workspace, size_t workspace_bytes,
+                               void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24) && world > 0, "bn_sync_fwd: bad sizes");
   NNL_CHECK_ARG(x && y && all_stats && save_mean && save_invstd, "bn_sync_fwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
@@ -597,19 +646,19 @@ extern "C" int nnl_bn_sync_fwd(const float* x, const float* all_stats, int world
   const long CG = C / VEC, total_v = rows * CG;
   if (VEC == 4)
     hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
-                       (int)CG, relu);
+                       (int)CG, relu, relu ? relu_mask : nullptr);
   else
     hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, x, scale, shift, residual, y, total_v,
-                       (int)CG, relu);
+                       (int)CG, relu, relu ? relu_mask : nullptr);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
 
-extern "C" int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                                      float* sums, int64_t rows, int64_t C, int relu, void* workspace, size_t workspace_bytes,
-                                      void* stream) {
+extern "C" int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const uint32_t* relu_mask, const float* x,
+                                      const float* mean, const float* invstd, float* sums, int64_t rows, int64_t C, int relu,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_sync_bwd_reduce: bad sizes");
-  NNL_CHECK_ARG(dy && x && mean && invstd && sums && (y || !relu), "bn_sync_bwd_reduce: null pointer");
+  NNL_CHECK_ARG(dy && x && mean && invstd && sums && (y || relu_mask || !relu), "bn_sync_bwd_reduce: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
     return nnl_set_error(NNL_ERR_WORKSPACE, "bn_sync_bwd_reduce: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -619,10 +668,10 @@ extern "C" int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const flo
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (relu ? 12.0 : 8.0));
   if (VEC == 4)
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
-                       (int)C, sh.L, relu);
+                       (int)C, sh.L, relu, relu_mask);
   else
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, dy, y, x, mean, invstd, part, (long)rows,
-                       (int)C, sh.L, relu);
+                       (int)C, sh.L, relu, relu_mask);
   NNL_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_sync_bwd_sums_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, (const float*)part, sh.gx, sums,
                      (int)C);
@@ -630,12 +679,14 @@ extern "C" int nnl_bn_sync_bwd_reduce(const float* dy, const float* y, const flo
   return NNL_OK;
 }
 
-extern "C" int nnl_bn_sync_bwd(const float* dy, const float* y, const float* x, const float* gamma, const float* mean,
+extern "C" int nnl_bn_sync_bwd(const float* dy, const float* y, const uint32_t* relu_mask, const float* x, const float* gamma,
+                               const float* mean,
                                const float* invstd, const float* local_sums, const float* global_sums, const float* all_stats,
                                int world, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows, int64_t C, int relu,
                                void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24) && world > 0, "bn_sync_bwd: bad sizes");
-  NNL_CHECK_ARG(dy && x && mean && invstd && dx && local_sums && global_sums && all_stats && (y || !relu), "bn_sync_bwd: null pointer");
+  NNL_CHECK_ARG(dy && x && mean && invstd && dx && local_sums && global_sums && all_stats && (y || relu_mask || !relu),
+                "bn_sync_bwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
     return nnl_set_error(NNL_ERR_WORKSPACE, "bn_sync_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -648,10 +699,10 @@ extern "C" int nnl_bn_sync_bwd(const float* dy, const float* y, const float* x, 
   const long CG = C / VEC, total_v = rows * CG;
   if (VEC == 4)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
-                       (int)CG, (int)C, relu);
+                       (int)CG, (int)C, relu, relu_mask);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(ew_grid(total_v, CG)), dim3(kBlock), 0, s, dy, y, x, coef, dx, dres, total_v,
-                       (int)CG, (int)C, relu);
+                       (int)CG, (int)C, relu, relu_mask);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

@@ -216,6 +216,11 @@ def _rows_view(x):
     raise ValueError('bn_act: unsupported input rank %d' % x.dim())
 
 
+def _relu_mask(rows, C, device):
+    "uninitialised keep-bit buffer for nnl_bn_fwd (1 bit per element, + 2 words of slack)"
+    return torch.empty((rows * C + 31) // 32 + 2, dtype=torch.int32, device=device)
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt, slot=None):
@@ -229,16 +234,17 @@ class _BNAct(torch.autograd.Function):
         invstd = torch.empty(C, dtype=torch.float32, device=xm.device)
         wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
+        mask = _relu_mask(rows, C, xm.device) if relu else None      # 1 bit / element for the backward's ReLU gate
         check(lib.nnl_bn_fwd(ptr(xm), ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
                              ptr(running_var), rows, C, float(eps), float(momentum), int(training), int(relu), ptr(nbt),
-                             ptr(ws), wsb, stream()))
-        ctx.save_for_backward(xm, y if relu else None, gamma, mean, invstd)
+                             ptr(mask), ptr(ws), wsb, stream()))
+        ctx.save_for_backward(xm, mask, gamma, mean, invstd)
         ctx.cfg = (training, relu, residual is not None, back)
         return back(y)
 
     @staticmethod
     def backward(ctx, dy):
-        xm, y, gamma, mean, invstd = ctx.saved_tensors
+        xm, mask, gamma, mean, invstd = ctx.saved_tensors
         training, relu, has_res, back = ctx.cfg
         dym = _rows_view(dy)[0]
         rows, C = xm.shape
@@ -248,8 +254,8 @@ class _BNAct(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=xm.device) if gamma is not None else None
         wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=xm.device)
-        check(lib.nnl_bn_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres), ptr(dgamma),
-                             ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
+        check(lib.nnl_bn_bwd(ptr(dym), None, ptr(mask), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dres),
+                             ptr(dgamma), ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
         if ctx.slot is not None and dres is not None:
             ctx.slot.tensor, dres = dres, None              # the block's first conv adds it to its dx (GradSlot)
         return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 8
@@ -282,16 +288,17 @@ class _SyncBNAct(torch.autograd.Function):
         y = torch.empty_like(xm)
         mean = torch.empty(C, dtype=torch.float32, device=dev)
         invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        mask = _relu_mask(rows, C, dev) if relu else None
         check(lib.nnl_bn_sync_fwd(ptr(xm), ptr(all_stats), world, ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd),
                                   ptr(running_mean), ptr(running_var), rows, C, float(eps), float(momentum), int(relu), ptr(nbt),
-                                  ptr(ws), wsb, stream()))
-        ctx.save_for_backward(xm, y if relu else None, gamma, mean, invstd, all_stats)
+                                  ptr(mask), ptr(ws), wsb, stream()))
+        ctx.save_for_backward(xm, mask, gamma, mean, invstd, all_stats)
         ctx.cfg = (relu, residual is not None, back, group, comm)
         return back(y)
 
     @staticmethod
     def backward(ctx, dy):
-        xm, y, gamma, mean, invstd, all_stats = ctx.saved_tensors
+        xm, mask, gamma, mean, invstd, all_stats = ctx.saved_tensors
         relu, has_res, back, group, comm = ctx.cfg
         dym = _rows_view(dy)[0]
         rows, C = xm.shape
@@ -299,14 +306,14 @@ class _SyncBNAct(torch.autograd.Function):
         wsb = int(lib.nnl_bn_workspace_bytes(rows, C))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
         sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
-        check(lib.nnl_bn_sync_bwd_reduce(ptr(dym), ptr(y), ptr(xm), ptr(mean), ptr(invstd), ptr(sums), rows, C, int(relu), ptr(ws),
-                                         wsb, stream()))
+        check(lib.nnl_bn_sync_bwd_reduce(ptr(dym), None, ptr(mask), ptr(xm), ptr(mean), ptr(invstd), ptr(sums), rows, C, int(relu),
+                                         ptr(ws), wsb, stream()))
         total = comm.all_reduce_sum(sums, group)                   # a new tensor; `sums` keeps the local values
         dx = torch.empty_like(xm)
         dres = torch.empty_like(xm) if (has_res and ctx.needs_input_grad[1]) else None
         dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
         dbeta = torch.empty(C, dtype=torch.float32, device=dev) if gamma is not None else None
-        check(lib.nnl_bn_sync_bwd(ptr(dym), ptr(y), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(sums), ptr(total),
+        check(lib.nnl_bn_sync_bwd(ptr(dym), None, ptr(mask), ptr(xm), ptr(gamma), ptr(mean), ptr(invstd), ptr(sums), ptr(total),
                                   ptr(all_stats), int(all_stats.shape[0]), ptr(dx), ptr(dres), ptr(dgamma), ptr(dbeta), rows, C,
                                   int(relu), ptr(ws), wsb, stream()))
         if ctx.slot is not None and dres is not None:
