@@ -56,9 +56,13 @@ int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
 
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
+  { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
-  hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(p.grid_m * p.grid_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+  if (BM == 64 && BN == 64 && p.variant == 1)
+    hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2, true>), dim3(p.grid_m * p.grid_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(p.grid_m * p.grid_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t s) {
+  { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
   p.grid_m = (int)nnl_cdiv(p.M, 64);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
   const int T = p.grid_m * p.grid_n;
@@ -147,8 +152,12 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t
   p.main_out = ws; p.main_slab_stride = (long)pl.tail_row0 * p.Nc;
   p.tail_out = ws + pl.main_floats; p.tail_slab_stride = (long)(p.M - pl.tail_row0) * p.Nc;
   const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
-  if (pl.bk == 32)
+  if (pl.bk == 32 && p.variant == 1)
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk == 32)
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+  else if (p.variant == 1)
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, true>), dim3(grid), dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();

@@ -39,6 +39,7 @@ struct IgemmTapsParams {
   // cut into tail_slices short k slices that spread evenly over all CUs; slices write partial slabs that a fixed-order
   // reduce kernel sums (deterministic).  tail rows start at tail_row0 (n_main_tiles is a multiple of grid_n).
   int bal, main_ks, n_main_tiles, tail_slices, tail_row0;
+  int variant;                         // 1: PIPE instantiation of the 64x64 kernel (A/B: tools/bench_conv.py --ab NNL_IGEMM_VARIANT=0,1)
   float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
   float* tail_out; long tail_slab_stride;      // tail_slices > 1: slabs [tail_slices][M - tail_row0][Nc]
   int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
@@ -53,7 +54,7 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
   return __builtin_bit_cast(f32x4, v);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
   static_assert(WGM * WGN == 4 && BK % 8 == 0, "config");
   constexpr int BKP = BK + 4;
@@ -168,14 +169,37 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     const float* As = lds[buf] + wm * WTM * BKP + frag_off;
     const float* Bs = lds[buf] + BM * BKP + wn * WTN * BKP + frag_off;
     if constexpr (kTwoAcc) {
+      if constexpr (!PIPE) {
 #pragma unroll
-      for (int kk = 0; kk < BK / 8; kk += 2) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + kk * 8), b0 = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + kk * 8 + 8), b1 = *reinterpret_cast<const f32x4*>(Bs + kk * 8 + 8);
+        for (int kk = 0; kk < BK / 8; kk += 2) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + kk * 8), b0 = *reinterpret_cast<const f32x4*>(Bs + kk * 8);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + kk * 8 + 8), b1 = *reinterpret_cast<const f32x4*>(Bs + kk * 8 + 8);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc2, 0, 0, 0);
+          }
+        }
+        return;
+      }
+      // software-pipelined over pairs of 8-wide k groups: the four ds_read_b128 of pair p+1 are issued before the eight
+      // MFMAs of pair p, so their LDS latency hides behind 512 MFMA cycles instead of 64
+      constexpr int NP = BK / 16;
+      f32x4 fa[2][2], fb[2][2];
+      fa[0][0] = *reinterpret_cast<const f32x4*>(As); fb[0][0] = *reinterpret_cast<const f32x4*>(Bs);
+      fa[0][1] = *reinterpret_cast<const f32x4*>(As + 8); fb[0][1] = *reinterpret_cast<const f32x4*>(Bs + 8);
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const int cur_s = pp & 1, nxt_s = cur_s ^ 1;
+        if (pp + 1 < NP) {
+          fa[nxt_s][0] = *reinterpret_cast<const f32x4*>(As + (pp + 1) * 16); fb[nxt_s][0] = *reinterpret_cast<const f32x4*>(Bs + (pp + 1) * 16);
+          fa[nxt_s][1] = *reinterpret_cast<const f32x4*>(As + (pp + 1) * 16 + 8); fb[nxt_s][1] = *reinterpret_cast<const f32x4*>(Bs + (pp + 1) * 16 + 8);
+          __builtin_amdgcn_sched_barrier(0);                 // keep the compiler from sinking them back behind the MFMAs
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc2, 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur_s][0][t], fb[cur_s][0][t], acc[0][0], 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur_s][1][t], fb[cur_s][1][t], acc2, 0, 0, 0);
         }
       }
       return;
