@@ -160,7 +160,7 @@ def main():
         pass
     roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                'kernel': 'igemm_rowk/igemm_kmajor (fp32 MFMA implicit-GEMM conv2d+linear fwd, dgrad, wgrad)',
+                'kernel': 'igemm_taps_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: fwd, dgrad, wgrad; incl. their slab reduces)',
                 'launches_per_step': conv_launches / max(n_prof, 1),
                 'avg_launch_ms': conv_ms / max(conv_launches, 1),
                 'flop_per_launch': conv_flop / max(conv_launches, 1),
