@@ -182,6 +182,11 @@ def main():
                        'last_loss': loss},
             'roofline': roofline,
         }
+        if learner.grad_sync is not None:                # data parallel: how the gradients reached the all-reduce buckets
+            gs = learner.grad_sync
+            out['config']['grad_buckets'] = len(gs.buckets)
+            out['config']['grads_written_in_place'] = '%d of %d tensors per step' % (
+                gs.direct_writes // max(gs.steps, 1), sum(len(b.params) for b in gs.buckets))
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(per_gpu_bs, args.sz)
         print(json.dumps(out))

@@ -79,6 +79,10 @@ class GradSync:
         """(Re)build buckets and hooks — call after freezing / unfreezing parameters."""
         for h in self._hooks:
             h.remove()
+        for b in getattr(self, 'buckets', []):
+            for p in b.params:
+                if hasattr(p, '_nnl_grad_dst'):
+                    del p._nnl_grad_dst
         self._hooks, self.buckets, self._where = [], [], {}
         params = [p for p in self.model.parameters() if p.requires_grad]
         seen, uniq = set(), []
@@ -96,13 +100,17 @@ class GradSync:
             for pi, p in enumerate(b.params):
                 self._where[id(p)] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+                # ops._Conv2d.backward writes the weight gradient straight into the bucket (no copy kernel) when it finds this
+                p._nnl_grad_dst = b.views[pi]
         self._active = False
+        self.direct_writes, self.steps = 0, 0           # gradients that arrived in place / backward passes (diagnostics)
 
     def begin(self):
         "Arm the hooks for one backward pass (Learner.train1minibatch calls this before the forward)."
         for b in self.buckets:
             b.pending, b.ready, b.handle = len(b.params), [False] * len(b.params), None
         self._active = True
+        self.steps += 1
 
     def _launch(self, b):
         # NNL_DIST_FORCE_ALLREDUCE=1: issue the collective even at world_size 1 (exercises the RCCL call path on a 1-GPU box)
@@ -116,7 +124,10 @@ class GradSync:
         b = self.buckets[bi]
         if b.ready[pi]:
             return
-        b.views[pi].copy_(p.grad)
+        if p.grad.data_ptr() == b.views[pi].data_ptr() and p.grad.stride() == b.views[pi].stride():
+            self.direct_writes += 1                     # produced in place by the wgrad kernel
+        else:
+            b.views[pi].copy_(p.grad)
         b.ready[pi] = True
         b.pending -= 1
         if b.pending == 0:

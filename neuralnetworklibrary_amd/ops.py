@@ -126,6 +126,7 @@ class _Conv2d(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, relu, slot=None):
         require_cuda(x, weight, bias)
         ctx.slot = slot
+        ctx.grad_dst = getattr(weight, '_nnl_grad_dst', None)     # data parallel: the flat all-reduce bucket (dist.GradSync)
         xn = _pad_c4(to_nhwc(_f32c(x) if x.dim() != 4 else x.float()))
         wn = _pad_c4(to_nhwc(weight.float()))
         N, H, W, C = xn.shape
@@ -171,7 +172,12 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.slot is not None:
             ctx.slot.tensor = None
         if ctx.needs_input_grad[1]:
-            dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
+            dst = ctx.grad_dst
+            if dst is not None and dst.dim() == 4 and g.K == K and ctx.c_in == g.C and dst.permute(0, 2, 3, 1).is_contiguous() \
+                    and tuple(dst.shape) == (g.K, g.C, g.R, g.S):
+                dwn = dst.permute(0, 2, 3, 1)               # the bucket segment, viewed KRSC: the kernel writes it in place
+            else:
+                dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
             ws_bytes = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dyn.device)
             check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
