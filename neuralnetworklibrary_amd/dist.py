@@ -65,6 +65,7 @@ class _Bucket:
         self.pending = len(params)
         self.ready = [False] * len(params)
         self.handle = None
+        self.averaged = False
 
 
 class GradSync:
@@ -108,14 +109,17 @@ class GradSync:
     def begin(self):
         "Arm the hooks for one backward pass (Learner.train1minibatch calls this before the forward)."
         for b in self.buckets:
-            b.pending, b.ready, b.handle = len(b.params), [False] * len(b.params), None
+            b.pending, b.ready, b.handle, b.averaged = len(b.params), [False] * len(b.params), None, False
         self._active = True
         self.steps += 1
 
     def _launch(self, b):
         # NNL_DIST_FORCE_ALLREDUCE=1: issue the collective even at world_size 1 (exercises the RCCL call path on a 1-GPU box)
         if world_size() > 1 or (dist.is_initialized() and os.environ.get('NNL_DIST_FORCE_ALLREDUCE') == '1'):
-            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            # RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG: sum, then finish() scales
+            b.averaged = dist.get_backend(self.group) == 'nccl'
+            op = dist.ReduceOp.AVG if b.averaged else dist.ReduceOp.SUM
+            b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         if not self._active:
@@ -153,7 +157,7 @@ class GradSync:
                 b.handle = None
             elif b.pending == len(b.params):
                 continue
-            if w > 1:
+            if w > 1 and not b.averaged:
                 b.flat.mul_(1.0 / w)
             for p, v in zip(b.params, b.views):
                 p.grad = v
