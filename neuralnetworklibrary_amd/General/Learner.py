@@ -317,15 +317,15 @@ class Learner(object):
                 y_pred = self.predict1minibatch(x_batch)
                 if isinstance(y_pred, tuple):
                     y_pred = y_pred[0]
+                # per-batch results stay on the device; ONE device->host copy after the loop (the reference copies and
+                # synchronises every minibatch: ARR(y_pred), Learner.py:356-372)
                 if self.target_type == 'cont':
-                    out.append(ARR(y_pred))
+                    out.append(y_pred)
                 elif self.target_type in ['cat', 'single_label', 'text_classify']:
-                    probs = ARR(y_pred) if not correct_probs else ARR(F.log_softmax(y_pred, dim=1).exp())
-                    out.append([probs, probs.argmax(axis=1)])
+                    out.append([y_pred if not correct_probs else F.log_softmax(y_pred, dim=1).exp(), None])
                 elif self.target_type == 'multi_label':
-                    sig = ARR(y_pred.sigmoid())
-                    probs = sig if correct_probs else ARR(y_pred)
-                    out.append([probs, np.around(sig).astype(int)])
+                    sig = y_pred.sigmoid()
+                    out.append([sig if correct_probs else y_pred, sig])
                 elif self.target_type == 'bbox':
                     anchors, reg, clas = y_pred
                     B, Cl, Sc = self.model.BBoxPredictor(x_batch, reg, clas, anchors, thresh, max_overlap,
@@ -334,9 +334,12 @@ class Learner(object):
                     ds = self.data.val_ds if which == 'val' else self.data.test_ds
                     out.append([list_mult(B, 1 / ds.images[j]['scale']), Cl, Sc])
         if self.target_type == 'cont':
-            return np.concatenate(out)
-        if self.target_type in ['cat', 'single_label', 'multi_label', 'text_classify']:
-            return [np.concatenate([o[0] for o in out]), np.concatenate([o[1] for o in out])]
+            return ARR(torch.cat(out))
+        if self.target_type in ['cat', 'single_label', 'text_classify']:
+            probs = ARR(torch.cat([o[0] for o in out]))
+            return [probs, probs.argmax(axis=1)]
+        if self.target_type == 'multi_label':
+            return [ARR(torch.cat([o[0] for o in out])), np.around(ARR(torch.cat([o[1] for o in out]))).astype(int)]
         return out
 
     def _allreduce_sums(self, values):
@@ -348,47 +351,56 @@ class Learner(object):
         return t.tolist()
 
     def evaluate(self, dataset_type, metrics=[]):
-        """Size-weighted mean loss (+ accuracy and metrics for 'val')  (General/Learner.py:395-485)."""
+        """Size-weighted mean loss (+ accuracy and metrics for 'val')  (General/Learner.py:395-485).
+        The reference synchronises 2-3 times per minibatch (`loss.item()`, the accuracy count, every metric); here the sums
+        are accumulated ON THE DEVICE in fp64 — the same additions of the same fp32 values in the same order, so the result
+        is bit-identical — and read back once per call."""
         use_end = any((m in end_metrics) for m in metrics if isinstance(m, str))
         self.model.eval()
-        total_loss, n_seen = 0., 0
+        dev = default_device()
+        n_seen = 0
+
+        def as_f64(v):
+            return v.detach().to(dev, torch.float64).reshape(()) if torch.is_tensor(v) else torch.tensor(float(v), dtype=torch.float64, device=dev)
 
         if dataset_type == 'train':
+            acc = torch.zeros((), dtype=torch.float64, device=dev)
             with torch.no_grad():
                 for x_batch, y_batch in self.data.train_dl:
                     bs = _batch_size(y_batch)
                     x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
-                    total_loss += bs * self.loss_func(self.predict1minibatch(x_batch), y_batch).item()
+                    acc += bs * as_f64(self.loss_func(self.predict1minibatch(x_batch), y_batch))
                     n_seen += bs
-            total_loss, n_seen = self._allreduce_sums([total_loss, n_seen])
+            total_loss, n_seen = self._allreduce_sums([acc.item(), n_seen])
             return total_loss / n_seen
 
         if dataset_type == 'val':
-            num_correct, Y, YPRED = 0, [], []
-            metric_values = np.zeros(len(metrics))
+            Y, YPRED = [], []
+            acc = torch.zeros(2 + len(metrics), dtype=torch.float64, device=dev)      # [loss, num_correct, metrics...]
             with torch.no_grad():
                 for x_batch, y_batch in self.data.val_dl:
                     bs = _batch_size(y_batch)
                     x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
                     y_pred = self.predict1minibatch(x_batch)
-                    total_loss += bs * self.loss_func(y_pred, y_batch).item()
+                    acc[0] += bs * as_f64(self.loss_func(y_pred, y_batch))
                     n_seen += bs
                     if use_end:
                         YPRED.append(y_pred); Y.append(y_batch)
                     for i, m in enumerate(metrics):
                         if isinstance(m, str) and m in end_metrics:
                             continue
-                        metric_values[i] += bs * m(y_pred, y_batch).item()
+                        acc[2 + i] += bs * as_f64(m(y_pred, y_batch))
                     if self.target_type in ['cat', 'single_label']:
-                        num_correct += (y_pred.max(dim=1)[1] == y_batch).sum().item()
+                        acc[1] += (y_pred.max(dim=1)[1] == y_batch).sum()
                     elif self.target_type == 'multi_label':
-                        num_correct += (y_pred.sigmoid().round() == y_batch).sum().item()
+                        acc[1] += (y_pred.sigmoid().round() == y_batch).sum()
             if use_end:
                 YPRED, Y = torch.cat(YPRED), torch.cat(Y)
                 for i, m in enumerate(metrics):
                     if isinstance(m, str) and m in end_metrics:
-                        metric_values[i] = n_seen * end_metrics[m]()(YPRED, Y).item()
-            sums = self._allreduce_sums([total_loss, n_seen, num_correct] + list(metric_values))
+                        acc[2 + i] = n_seen * as_f64(end_metrics[m]()(YPRED, Y))
+            host = acc.tolist()                                                      # the only device->host sync
+            sums = self._allreduce_sums([host[0], n_seen, host[1]] + host[2:])
             total_loss, n_seen, num_correct = sums[0], sums[1], sums[2]
             metric_values = np.array(sums[3:]) / n_seen
             results = [total_loss / n_seen]

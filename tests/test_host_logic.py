@@ -150,3 +150,33 @@ def test_checkpoint_round_trip_keys():
     learner.fit(1e-1, 1)
     learner.load('ck', saved_optimizer=True)
     assert np.abs(flat(learner.model) - w).max() == 0.0
+
+
+def test_predict_and_evaluate_single_sync_paths_match_per_batch_arithmetic():
+    """Learner.predict / evaluate keep per-batch results on the device and copy once: same values as the reference's
+    per-minibatch ARR(...) / .item() arithmetic (General/Learner.py:286-485)."""
+    import torch.nn.functional as F
+    from neuralnetworklibrary_amd.General.Core import make_model_basic
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    Learner.verbose = False
+    g = torch.Generator().manual_seed(0)
+    batches = [(torch.randn(n, 6, generator=g), torch.randint(0, 3, (n,), generator=g)) for n in (8, 8, 5)]
+    class D:
+        target_type, bs, categories = 'single_label', 8, ['a', 'b', 'c']
+        train_dl = val_dl = batches
+    d = D()
+    torch.manual_seed(1)
+    net = make_model_basic(nn.Sequential(nn.Linear(6, 10), nn.Tanh(), nn.Linear(10, 3)))
+    learner = Learner('/tmp/nnl_host_logic', d, net, optimizer='SGD')
+    probs, labels = learner.predict('val')
+    net.eval()
+    with torch.no_grad():
+        want = torch.cat([F.log_softmax(net(x), dim=1).exp() for x, _ in batches]).numpy()
+        tot = sum(len(y) * F.cross_entropy(net(x), y).item() for x, y in batches)
+        correct = sum((net(x).max(dim=1)[1] == y).sum().item() for x, y in batches)
+    assert np.array_equal(probs, want) and np.array_equal(labels, want.argmax(axis=1))
+    raw, _ = learner.predict('val', correct_probs=False)
+    assert raw.shape == (21, 3) and not np.allclose(raw, want)
+    loss, acc = learner.evaluate('val')
+    assert loss == tot / 21 and acc == correct / 21
+    assert learner.evaluate('train') == tot / 21
