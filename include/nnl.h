@@ -236,10 +236,12 @@ int nnl_retina_loss_bwd(const float* anchors, const float* reg, const float* cla
  * GEMM done by the caller with nnl_conv2d_fwd as a 1x1 conv).  Padded operands (the GEMM k dimension must be a
  * multiple of 32): Hp = nnl_lstm_padded_hidden(H) = ceil32(H), Gp = nnl_lstm_padded_gates(H) = ceil32(4H);
  * w_hh_pad [4H, Hp] = (dropped) W_hh with zero-padded rows; h0, c0 [B,H].  Outputs y [T,B,H] (h_t), cy [T,B,H] (c_t)
- * and gates [T,B,4H] (ACTIVATED i,f,g,o) — the last two are saved for backward. */
+ * and gates [T,B,4H] (ACTIVATED i,f,g,o) — the last two are saved for backward.
+ * One kernel launch per timestep: the recurrent GEMM runs in k slices over <= 256 workgroups and the workgroup that finishes
+ * a tile last (atomic ticket, nobody waits) sums the slices in a fixed order and applies the cell (csrc/lstm.hip). */
 int64_t nnl_lstm_padded_hidden(int64_t H);
 int64_t nnl_lstm_padded_gates(int64_t H);
-size_t nnl_lstm_workspace_bytes(int64_t B, int64_t H);
+size_t nnl_lstm_workspace_bytes(int64_t T, int64_t B, int64_t H);
 int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
                  float* gates, int64_t T, int64_t B, int64_t H, void* workspace, size_t workspace_bytes, void* stream);
 /* BPTT: dy [T,B,H] (may be NULL), dhT / dcT [B,H] (may be NULL = 0), w_hh_t_pad [H, Gp] = W_hh^T with zero-padded rows.

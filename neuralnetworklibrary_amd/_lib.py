@@ -64,7 +64,7 @@ SIGNATURES = {
     'nnl_retina_loss_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, f32, f32, f32, c_p]),
     'nnl_lstm_padded_hidden': (i64, [i64]),
     'nnl_lstm_padded_gates': (i64, [i64]),
-    'nnl_lstm_workspace_bytes': (sz, [i64, i64]),
+    'nnl_lstm_workspace_bytes': (sz, [i64, i64, i64]),
     'nnl_lstm_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p]),
     'nnl_lstm_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p]),
     'nnl_embedding_rowmask_fwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, c_p, c_p]),

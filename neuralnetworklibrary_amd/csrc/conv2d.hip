@@ -413,6 +413,21 @@ int nnl_internal_gemm_nt_splitk(const float* a, const float* b, float* y_slabs, 
   return launch_taps<64, 64, 32>(q, s);
 }
 
+int nnl_internal_lstm_step(IgemmTapsParams q, int epi, hipStream_t s) {
+  if ((epi != 1 && epi != 2) || q.M <= 0 || q.C % 32 != 0 || q.lstm.H <= 0 || q.lstm.counters == nullptr)
+    return nnl_set_error(NNL_ERR_INVALID_ARG, "lstm_step: bad arguments");
+  q.grid_m = (int)nnl_cdiv(q.M, 64);
+  q.grid_n = epi == 1 ? (int)nnl_cdiv(q.lstm.H, 16) : (int)nnl_cdiv(q.lstm.H, 64);
+  q.bal = 0;
+  const dim3 grid(q.grid_m * q.grid_n, q.ksplit > 1 ? q.ksplit : 1), block(256);
+  if (epi == 1)
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true, 1>), grid, block, 0, s, q);
+  else
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true, 2>), grid, block, 0, s, q);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
 size_t nnl_internal_gemm_tn_workspace_bytes(int Mc, int Nc, long Kp) {
   const WgradPlan pl = plan_wgrad(Mc, Nc, Kp);
   return pl.splits > 1 ? (size_t)pl.splits * Mc * Nc * sizeof(float) : 0;

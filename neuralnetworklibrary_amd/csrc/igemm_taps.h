@@ -20,6 +20,27 @@
 
 #define IGEMM_MAX_TAPS 49
 
+// LSTM recurrence fused into the GEMM (EPI = 1 forward, 2 backward; lstm.hip): the workgroup that finishes LAST among the
+// k slices of an output tile (atomic ticket — nobody ever waits, so no deadlock is possible) sums the slabs in slice order
+// (deterministic, whoever arrives last) and applies the pointwise cell to its tile.
+//  EPI 1: logical column nl of tile j is gate (nl >> 4) of hidden unit j*16 + (nl & 15) — the B rows are GATHERED so that a
+//         64-column tile holds all four gates of 16 units while W_hh, gx and the gate tape keep torch's [4H] = (gate, unit)
+//         layout.  Writes the activated gates, c_t, h_t and the next step's padded A operand.
+//  EPI 2: columns are hidden units; dh_t = dy_t + tile, then the cell backward: dgates_t (pre-activation grads), dc_{t-1}.
+struct LstmEpi {
+  int H, Hp, Gp;
+  int* counters;             // [tiles of this timestep], zero before the launch
+  const float* gx;           // EPI 1: [B,4H] input projections of this timestep
+  const float* c_prev;       // [B,H]  c_{t-1}
+  float* gates;              // EPI 1: out [B,4H] activated;  EPI 2: in (const use)
+  float* c;                  // EPI 1: out c_t [B,H];          EPI 2: in c_t
+  float* h;                  // EPI 1: out h_t [B,H]
+  float* hpad;               // EPI 1: out [B,Hp] (columns >= H are never written: zeroed once by the host)
+  const float* dy;           // EPI 2: [B,H] or null
+  float* dc;                 // EPI 2: in/out [B,H]
+  float* dgates;             // EPI 2: out [B,Gp]
+};
+
 struct IgemmTapsParams {
   const float* a; const float* b; float* y; const float* bias; const float* add;
   unsigned a_bytes, b_bytes;
@@ -39,6 +60,7 @@ struct IgemmTapsParams {
   // cut into tail_slices short k slices that spread evenly over all CUs; slices write partial slabs that a fixed-order
   // reduce kernel sums (deterministic).  tail rows start at tail_row0 (n_main_tiles is a multiple of grid_n).
   int bal, main_ks, n_main_tiles, tail_slices, tail_row0;
+  LstmEpi lstm;                        // EPI != 0 instantiations only
   int variant;                         // 1: PIPE instantiation of the 64x64 kernel (A/B: tools/bench_conv.py --ab NNL_IGEMM_VARIANT=0,1)
   float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
   float* tail_out; long tail_slab_stride;      // tail_slices > 1: slabs [tail_slices][M - tail_row0][Nc]
@@ -49,13 +71,23 @@ struct IgemmTapsParams {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+template <int POL>
+__device__ __forceinline__ f32x4 buf_load4_policy(__amdgpu_buffer_rsrc_t rsrc, unsigned voff) {
+  const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, 0, POL));
+  return __builtin_bit_cast(f32x4, v);
+}
+#define buf_load4_pol(rsrc, voff, pol) buf_load4_policy<pol>(rsrc, voff)
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
   const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
   return __builtin_bit_cast(f32x4, v);
 }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false>
+__device__ __forceinline__ float nnl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
+  static_assert(EPI == 0 || (BM == 64 && BN == 64), "the LSTM epilogue is written for the 64x64 tile");
   static_assert(WGM * WGN == 4 && BK % 8 == 0, "config");
   constexpr int BKP = BK + 4;
   constexpr int KC = BK / 4;
@@ -125,8 +157,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   unsigned b_off[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    const int nr = n0 + lrow + i * RPP;
-    b_off[i] = nr < p.Nc ? (unsigned)(nr * p.b_row_stride + kc * 4) * 4u : 0xFFFFFFFFu;
+    int nr = n0 + lrow + i * RPP;
+    bool okr = nr < p.Nc;
+    if constexpr (EPI == 1) {                      // gate-gathered rows: (gate, unit) -> W_hh row gate*H + unit
+      const int nl = lrow + i * RPP, u = tile_n * 16 + (nl & 15);
+      okr = u < p.lstm.H;
+      nr = (nl >> 4) * p.lstm.H + u;
+    }
+    b_off[i] = okr ? (unsigned)(nr * p.b_row_stride + kc * 4) * 4u : 0xFFFFFFFFu;
   }
 
   f32x4 ra[PA], rb[PB];
@@ -259,6 +297,96 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[0][0][e] += acc2[e];
   }
+  if constexpr (EPI != 0) {
+    // ---- fused LSTM cell ----------------------------------------------------------------------------------------------
+    constexpr int LDT = 68;
+    float* tl = &lds[0][0];                          // 64 x 68 floats: the k loop is over (it ended with a barrier)
+    __shared__ int ticket;
+    const int Nlog = p.grid_n * 64;
+    const int cl = wn * 32 + (lane & 31);
+    if (nslices > 1) {
+      // Cross-workgroup hand-over WITHOUT cache-wide fences: a device-scope __threadfence() writes back and invalidates the
+      // whole L2 of the XCD (measured: 4x slower steps, W_hh loses its L2 residency).  Instead the slab is written with
+      // agent-scope (write-through) atomic stores, every wave drains its stores (vmcnt 0) before the workgroup takes its
+      // ticket, and the finishing workgroup reads the slabs with agent-scope loads that bypass its own L2.
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)((long)nslices * p.slab_stride * 4), 0x00020000);
+      constexpr int kSc1 = 1 << 4;                   // gfx940+ cache policy bit: device (agent) scope — write-through / L2 bypass
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm * 32 + (e & 3) + 8 * (e >> 2) + (lane >> 5) * 4;
+        const long off = (long)kslice * p.slab_stride + (long)(m0 + rl) * Nlog + n0 + cl;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][0][e]), rs, (m0 + rl < p.M) ? (int)(off * 4) : -1, 0, kSc1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) ticket = __hip_atomic_fetch_add(&p.lstm.counters[logical], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (ticket != nslices - 1) return;             // someone else finishes this tile
+      // sum the slices in slice order (deterministic whoever is last): 4 float4 per thread, all loads in flight together
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = (idx4 & 15) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + rl < p.M) {
+          f32x4 part[8];
+          const int ns = nslices < 8 ? nslices : 8;
+#pragma unroll
+          for (int sl = 0; sl < 8; ++sl)
+            if (sl < ns) part[sl] = buf_load4_pol(rs, (unsigned)(((long)sl * p.slab_stride + (long)(m0 + rl) * Nlog + n0 + c4) * 4), kSc1);
+#pragma unroll
+          for (int sl = 0; sl < 8; ++sl)
+            if (sl < ns) v += part[sl];
+          for (int sl = 8; sl < nslices; ++sl)
+            v += buf_load4_pol(rs, (unsigned)(((long)sl * p.slab_stride + (long)(m0 + rl) * Nlog + n0 + c4) * 4), kSc1);
+        }
+        *reinterpret_cast<f32x4*>(tl + rl * LDT + c4) = v;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int rl = wm * 32 + (e & 3) + 8 * (e >> 2) + (lane >> 5) * 4;
+        tl[rl * LDT + cl] = acc[0][0][e];
+      }
+    }
+    __syncthreads();
+    const LstmEpi& L = p.lstm;
+    const int H = L.H;
+    if constexpr (EPI == 1) {
+      for (int idx = tid; idx < 64 * 16; idx += 256) {
+        const int rl = idx >> 4, j = idx & 15;
+        const int b = m0 + rl, u = tile_n * 16 + j;
+        if (b >= p.M || u >= H) continue;
+        const long g0 = (long)b * 4 * H + u, bu = (long)b * H + u;
+        const float gi = nnl_sigmoid(L.gx[g0] + tl[rl * LDT + j]);
+        const float gf = nnl_sigmoid(L.gx[g0 + H] + tl[rl * LDT + 16 + j]);
+        const float gg = tanhf(L.gx[g0 + 2L * H] + tl[rl * LDT + 32 + j]);
+        const float go = nnl_sigmoid(L.gx[g0 + 3L * H] + tl[rl * LDT + 48 + j]);
+        const float cn = gf * L.c_prev[bu] + gi * gg;
+        const float hn = go * tanhf(cn);
+        L.gates[g0] = gi; L.gates[g0 + H] = gf; L.gates[g0 + 2L * H] = gg; L.gates[g0 + 3L * H] = go;
+        L.c[bu] = cn;
+        L.h[bu] = hn;
+        L.hpad[(long)b * L.Hp + u] = hn;
+      }
+    } else {
+      for (int idx = tid; idx < 64 * 64; idx += 256) {
+        const int rl = idx >> 6, j = idx & 63;
+        const int b = m0 + rl, u = n0 + j;
+        if (b >= p.M || u >= H) continue;
+        const long g0 = (long)b * 4 * H + u, bu = (long)b * H + u;
+        const float gi = L.gates[g0], gf = L.gates[g0 + H], gg = L.gates[g0 + 2L * H], go = L.gates[g0 + 3L * H];
+        const float dh = (L.dy ? L.dy[bu] : 0.f) + tl[rl * LDT + j];
+        const float tc = tanhf(L.c[bu]);
+        const float dcn = L.dc[bu] + dh * go * (1.f - tc * tc);
+        float* dg = L.dgates + (long)b * L.Gp;
+        dg[u] = dcn * gg * (gi * (1.f - gi));
+        dg[H + u] = dcn * L.c_prev[bu] * (gf * (1.f - gf));
+        dg[2 * H + u] = dcn * gi * (1.f - gg * gg);
+        dg[3 * H + u] = dh * tc * (go * (1.f - go));
+        L.dc[bu] = dcn * gf;
+      }
+    }
+    return;
+  }
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
 #pragma unroll
@@ -291,3 +419,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     }
   }
 }
+
+// One LSTM timestep (defined in conv2d.hip, where the kernel templates are instantiated): epi 1 = forward (q.M = batch,
+// q.C = Hp, grid_n = ceil(H/16) gate-gathered tiles), epi 2 = backward (q.Nc = H, q.C = Gp).  q.ksplit k slices per tile
+// write slabs q.y[ksplit][M][grid_n*64]; q.lstm.counters must be zero.
+int nnl_internal_lstm_step(IgemmTapsParams q, int epi, hipStream_t s);

@@ -1,51 +1,29 @@
 // K5 — the recurrence of one (weight-dropped) LSTM layer: WeightDropLSTM1.forward -> nn.LSTM (cuDNN RNN in the
 // reference; Applications/Text.py:495-513, :535-551), forward and backward through time.
 //
-// The time loop lives HERE (one C call per layer per direction, no Python per-step overhead).  Each timestep is
-//   (1) one skinny fp32-MFMA GEMM  h_{t-1} [B,H] x W_hh^T  (fwd)  /  dgates_t [B,4H] x W_hh  (bwd), launched with SPLIT-K
-//       so that the 64x64 output tiles x k-ranges give <= 256 workgroups (the plain tile grid would occupy 18-72 of the 256
-//       CUs); every split writes its own fp32 slab;
-//   (2) one fused pointwise cell kernel that ALSO performs the fixed-order slab reduction (and adds the input projection
-//       gx_t), so split-K costs no extra launch and stays bitwise reproducible.
+// The time loop lives HERE (one C call per layer per direction, no Python per-step overhead).  Each timestep needs a skinny
+// fp32-MFMA GEMM  h_{t-1} [B,H] x W_hh^T  (fwd)  /  dgates_t [B,4H] x W_hh  (bwd), launched with SPLIT-K so that the 64x64
+// output tiles x k-ranges give <= 256 workgroups (the plain tile grid would occupy 18-72 of the 256 CUs), and the pointwise
+// cell, which needs the complete sums:
+//   forward : ONE launch per timestep (igemm_taps_kernel EPI 1) — tiles hold the 4 gates of 16 hidden units (gathered B
+//             rows), slices write fp32 slabs, and the workgroup that takes the last ticket of a tile sums the slabs in slice
+//             order (bitwise reproducible) and applies the cell.  Nobody waits for anybody: no deadlock is possible.
+//             19.8 us per step against ~30 us for GEMM + separate cell kernel.
+//   backward: two launches per timestep (GEMM, then a cell kernel that also sums the slabs).  The fused variant exists
+//             (EPI 2, NNL_LSTM_FUSED_BWD=1) but is slower: dh has only 18 output tiles, so the whole pointwise backward
+//             would run on 18 CUs (52 us vs ~25 us).
 // The input projections for all timesteps (gx) and the weight gradients are single large GEMMs outside the loop
 // (ops_text.py).  Gate order i,f,g,o and the cell equations are torch's:
 //   c_t = s(f)*c_{t-1} + s(i)*tanh(g);  h_t = s(o)*tanh(c_t).
 // Per step: 2*B*4H*H flop (677 MFLOP at B=64, H=1150) against 4H*H*4 B of W_hh (21 MB, L2 / Infinity-Cache resident
 // across steps): latency-bound; a persistent W_hh-resident kernel is the planned upgrade.
-#include "igemm.h"
+#include "igemm_taps.h"
 
 namespace {
 
 constexpr int kBlock = 256;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-// pre-activation gates = gx + sum_s slab[s]; writes activated gates [B,4H], c [B,H], h [B,H], hpad [B,Hp] (zero pad)
-__global__ void lstm_cell_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ slabs, int nslab,
-                                     long slab_stride, float* __restrict__ gates, const float* __restrict__ c_prev,
-                                     float* __restrict__ c, float* __restrict__ h, float* __restrict__ hpad, int B, int H,
-                                     int Hp) {
-  const int total = B * Hp;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int b = i / Hp, u = i - b * Hp;
-    if (u >= H) { hpad[i] = 0.f; continue; }
-    const long base = (long)b * 4 * H + u;
-    float pre[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float v = gx[base + (long)k * H];
-      for (int s = 0; s < nslab; ++s) v += slabs[s * slab_stride + base + (long)k * H];
-      pre[k] = v;
-    }
-    const float gi = sigmoidf_(pre[0]), gf = sigmoidf_(pre[1]), gg = tanhf(pre[2]), go = sigmoidf_(pre[3]);
-    const float cn = gf * c_prev[b * H + u] + gi * gg;
-    const float hn = go * tanhf(cn);
-    gates[base] = gi; gates[base + H] = gf; gates[base + 2L * H] = gg; gates[base + 3L * H] = go;
-    c[b * H + u] = cn;
-    h[b * H + u] = hn;
-    hpad[i] = hn;
-  }
-}
 
 __global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int H, int Hp) {
   const int total = B * Hp;
@@ -110,16 +88,32 @@ int pick_splits(long M, long N, long nk) {
   return (int)s;
 }
 
-struct Plan { int Hp, Gp, sf, sb; long fwd_slab, bwd_slab; };
+struct Plan { int Hp, Gp, sf, sb, tf, tb; long fwd_slab, bwd_slab; };
 Plan make_plan(long B, long H) {
   Plan p;
   p.Hp = (int)ceil32(H);
   p.Gp = (int)ceil32(4 * H);
-  p.sf = pick_splits(B, 4 * H, p.Hp / 32);
+  p.tf = (int)(nnl_cdiv(B, 64) * nnl_cdiv(H, 16));          // forward tiles: 16 hidden units x 4 gates each
+  p.tb = (int)(nnl_cdiv(B, 64) * nnl_cdiv(H, 64));          // backward tiles: 64 hidden units
+  p.sf = pick_splits(B, 64 * nnl_cdiv(H, 16), p.Hp / 32);
   p.sb = pick_splits(B, H, p.Gp / 32);
-  p.fwd_slab = B * 4 * H;
-  p.bwd_slab = B * H;
+  p.fwd_slab = B * 64 * nnl_cdiv(H, 16);                    // [B][logical columns]
+  p.bwd_slab = B * 64 * nnl_cdiv(H, 64);
   return p;
+}
+
+// fills the GEMM part of a fused step: y_slabs[ks][M][grid_n*64] = a[M][K] * b[rows][K]^T
+IgemmTapsParams step_params(const float* a, const float* b, float* slabs, int M, int Nc, int K, long b_rows, int ks,
+                            long slab_stride) {
+  IgemmTapsParams q{};
+  q.a = a; q.b = b; q.y = slabs; q.bias = nullptr; q.add = nullptr;
+  q.a_bytes = (unsigned)((long)M * K * 4); q.b_bytes = (unsigned)(b_rows * K * 4);
+  q.H = 1; q.W = 1; q.C = K; q.P = 1; q.Q = 1; q.in_stride = 1; q.ih0 = 0; q.iw0 = 0;
+  q.OH = 1; q.OW = 1; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
+  q.M = M; q.Nc = Nc; q.b_row_stride = K; q.relu = 0; q.ntaps = 1;
+  q.tap_dh[0] = 0; q.tap_dw[0] = 0; q.tap_aoff[0] = 0; q.tap_woff[0] = 0;
+  q.ksplit = ks; q.slab_stride = slab_stride;
+  return q;
 }
 
 }  // namespace
@@ -127,12 +121,17 @@ Plan make_plan(long B, long H) {
 extern "C" int64_t nnl_lstm_padded_hidden(int64_t H) { return ceil32(H); }
 extern "C" int64_t nnl_lstm_padded_gates(int64_t H) { return ceil32(4 * H); }
 
-extern "C" size_t nnl_lstm_workspace_bytes(int64_t B, int64_t H) {
-  if (B <= 0 || H <= 0) return 0;
-  const Plan p = make_plan(B, H);
-  const long fwd = 2 * B * p.Hp + (long)p.sf * p.fwd_slab;
-  const long bwd = (long)p.sb * p.bwd_slab + B * H;
-  return (size_t)(fwd > bwd ? fwd : bwd) * sizeof(float);
+// workspace (floats): forward  [2 x B*Hp h ping-pong][sf slabs][T*tf int counters]
+//                     backward [sb slabs][B*H][T*tb int counters]
+static size_t lstm_ws_floats(const Plan& p, long T, long B, long H) {
+  const long fwd = 2 * B * p.Hp + (long)p.sf * p.fwd_slab + T * p.tf;
+  const long bwd = (long)p.sb * p.bwd_slab + B * H + T * p.tb;
+  return (size_t)(fwd > bwd ? fwd : bwd);
+}
+
+extern "C" size_t nnl_lstm_workspace_bytes(int64_t T, int64_t B, int64_t H) {
+  if (T <= 0 || B <= 0 || H <= 0) return 0;
+  return lstm_ws_floats(make_plan(B, H), T, B, H) * sizeof(float);
 }
 
 extern "C" int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
@@ -140,23 +139,32 @@ extern "C" int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float*
                             void* stream) {
   NNL_CHECK_ARG(T > 0 && B > 0 && H > 0 && 4 * H < (1 << 24), "lstm_fwd: bad sizes");
   NNL_CHECK_ARG(gx && w_hh_pad && h0 && c0 && y && cy && gates, "lstm_fwd: null pointer");
-  if (workspace == nullptr || workspace_bytes < nnl_lstm_workspace_bytes(B, H))
+  if (workspace == nullptr || workspace_bytes < nnl_lstm_workspace_bytes(T, B, H))
     return nnl_set_error(NNL_ERR_WORKSPACE, "lstm_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, H);
   float* hbuf[2] = {(float*)workspace, (float*)workspace + B * p.Hp};
   float* slabs = (float*)workspace + 2 * B * p.Hp;
+  int* counters = (int*)(slabs + (long)p.sf * p.fwd_slab);
   const long BH = B * H, BG = B * 4 * H;
   NnlProfScope prof(NNL_PROF_LSTM, s, 2.0 * T * B * 4.0 * H * H);
   hipLaunchKernelGGL(pad_copy_kernel, dim3(ew_grid(B * p.Hp)), dim3(kBlock), 0, s, h0, hbuf[0], (int)B, (int)H, p.Hp);
   NNL_CHECK_LAUNCH();
+  NNL_CHECK_HIP(hipMemsetAsync(hbuf[1], 0, sizeof(float) * B * p.Hp, s));          // pad columns stay zero
+  NNL_CHECK_HIP(hipMemsetAsync(counters, 0, sizeof(int) * T * p.tf, s));
   for (long t = 0; t < T; ++t) {
-    int st = nnl_internal_gemm_nt_splitk(hbuf[t & 1], w_hh_pad, slabs, (int)B, (int)(4 * H), p.Hp, p.sf, s);
+    // one launch per timestep: gates = gx_t + h_{t-1} W_hh^T in sf k slices; the last slice of a tile applies the cell
+    IgemmTapsParams q = step_params(hbuf[t & 1], w_hh_pad, slabs, (int)B, (int)(4 * H), p.Hp, 4 * H, p.sf, p.fwd_slab);
+    q.lstm.H = (int)H; q.lstm.Hp = p.Hp; q.lstm.Gp = p.Gp;
+    q.lstm.counters = counters + t * p.tf;
+    q.lstm.gx = gx + t * BG;
+    q.lstm.c_prev = t == 0 ? c0 : cy + (t - 1) * BH;
+    q.lstm.gates = gates + t * BG;
+    q.lstm.c = cy + t * BH;
+    q.lstm.h = y + t * BH;
+    q.lstm.hpad = hbuf[(t + 1) & 1];
+    int st = nnl_internal_lstm_step(q, 1, s);
     if (st) return st;
-    const float* c_prev = t == 0 ? c0 : cy + (t - 1) * BH;
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(ew_grid(B * p.Hp)), dim3(kBlock), 0, s, gx + t * BG, (const float*)slabs, p.sf,
-                       p.fwd_slab, gates + t * BG, c_prev, cy + t * BH, y + t * BH, hbuf[(t + 1) & 1], (int)B, (int)H, p.Hp);
-    NNL_CHECK_LAUNCH();
   }
   return NNL_OK;
 }
@@ -166,28 +174,58 @@ extern "C" int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT,
                             int64_t B, int64_t H, void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(T > 0 && B > 0 && H > 0, "lstm_bwd: bad sizes");
   NNL_CHECK_ARG(gates && cy && c0 && w_hh_t_pad && dgates_pad && dh0 && dc0, "lstm_bwd: null pointer");
-  if (workspace == nullptr || workspace_bytes < nnl_lstm_workspace_bytes(B, H))
+  if (workspace == nullptr || workspace_bytes < nnl_lstm_workspace_bytes(T, B, H))
     return nnl_set_error(NNL_ERR_WORKSPACE, "lstm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const Plan p = make_plan(B, H);
   const long BH = B * H, BG = B * 4 * H, BGp = B * (long)p.Gp;
-  float* slabs = (float*)workspace;              // [sb][B][H]: split-K partials of dh_{t-1}
+  float* slabs = (float*)workspace;              // [sb][B][tiles*64]: split-K partials of dh_{t}
+  int* counters = (int*)(slabs + (long)p.sb * p.bwd_slab + BH);
   float* dc = dc0;                               // running d loss / d c_{t-1}, ends as dc0
   NnlProfScope prof(NNL_PROF_LSTM, s, 2.0 * T * B * 4.0 * H * H);
   if (dcT) NNL_CHECK_HIP(hipMemcpyAsync(dc, dcT, sizeof(float) * BH, hipMemcpyDeviceToDevice, s));
   else NNL_CHECK_HIP(hipMemsetAsync(dc, 0, sizeof(float) * BH, s));
-  for (long t = T - 1; t >= 0; --t) {
-    const float* c_prev = t == 0 ? c0 : cy + (t - 1) * BH;
-    const bool last = t == T - 1;                // recurrent term at the last step = dhT (or nothing)
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_grid(BH)), dim3(kBlock), 0, s, dy ? dy + t * BH : nullptr,
-                       last ? dhT : (const float*)slabs, last ? (dhT ? 1 : 0) : p.sb, last ? 0L : p.bwd_slab, gates + t * BG,
-                       cy + t * BH, c_prev, dc, dgates_pad + t * BGp, (int)B, (int)H, p.Gp);
+  NNL_CHECK_HIP(hipMemsetAsync(counters, 0, sizeof(int) * T * p.tb, s));
+  const char* e_f = getenv("NNL_LSTM_FUSED_BWD");              // tuning hook; default: two launches per backward timestep
+  const bool fused_bwd = e_f && atoi(e_f) == 1;
+  if (fused_bwd) {
+    // t = T-1: no recurrent term from a later step (only dhT, if any): the stand-alone cell kernel
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_grid(BH)), dim3(kBlock), 0, s, dy ? dy + (T - 1) * BH : nullptr, dhT,
+                       dhT ? 1 : 0, 0L, gates + (T - 1) * BG, cy + (T - 1) * BH, T == 1 ? c0 : cy + (T - 2) * BH, dc,
+                       dgates_pad + (T - 1) * BGp, (int)B, (int)H, p.Gp);
     NNL_CHECK_LAUNCH();
-    // dh_{t-1} = dgates_t [B,Gp] * W_hh [Gp(4H),H]  ==  gemm_nt(a = dgates_t, b = W_hh^T padded [H,Gp]) in sb k-ranges
-    int st = nnl_internal_gemm_nt_splitk(dgates_pad + t * BGp, w_hh_t_pad, slabs, (int)B, (int)H, p.Gp, p.sb, s);
+    for (long t = T - 2; t >= 0; --t) {
+      // one launch: dh_t = dy_t + dgates_{t+1} [B,Gp] * W_hh [Gp,H] in sb k slices; the last slice of a tile runs the cell
+      // backward of its 64 hidden units.  Measured SLOWER than two launches (52 vs ~25 us): only 18 output tiles exist, so
+      // the whole pointwise backward lands on 18 CUs.
+      IgemmTapsParams q = step_params(dgates_pad + (t + 1) * BGp, w_hh_t_pad, slabs, (int)B, (int)H, p.Gp, H, p.sb, p.bwd_slab);
+      q.lstm.H = (int)H; q.lstm.Hp = p.Hp; q.lstm.Gp = p.Gp;
+      q.lstm.counters = counters + t * p.tb;
+      q.lstm.dy = dy ? dy + t * BH : nullptr;
+      q.lstm.gates = const_cast<float*>(gates) + t * BG;
+      q.lstm.c = const_cast<float*>(cy) + t * BH;
+      q.lstm.c_prev = t == 0 ? c0 : cy + (t - 1) * BH;
+      q.lstm.dc = dc;
+      q.lstm.dgates = dgates_pad + t * BGp;
+      int st = nnl_internal_lstm_step(q, 2, s);
+      if (st) return st;
+    }
+    int st = nnl_internal_gemm_nt_splitk(dgates_pad, w_hh_t_pad, slabs, (int)B, (int)H, p.Gp, p.sb, s);
     if (st) return st;
+  } else {
+    for (long t = T - 1; t >= 0; --t) {
+      const float* c_prev = t == 0 ? c0 : cy + (t - 1) * BH;
+      const bool last = t == T - 1;              // recurrent term at the last step = dhT (or nothing)
+      hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_grid(BH)), dim3(kBlock), 0, s, dy ? dy + t * BH : nullptr,
+                         last ? dhT : (const float*)slabs, last ? (dhT ? 1 : 0) : p.sb, last ? 0L : BH, gates + t * BG,
+                         cy + t * BH, c_prev, dc, dgates_pad + t * BGp, (int)B, (int)H, p.Gp);
+      NNL_CHECK_LAUNCH();
+      // dh_{t-1} = dgates_t [B,Gp] * W_hh [Gp(4H),H]  ==  gemm_nt(a = dgates_t, b = W_hh^T padded [H,Gp]) in sb k-ranges
+      int st = nnl_internal_gemm_nt_splitk(dgates_pad + t * BGp, w_hh_t_pad, slabs, (int)B, (int)H, p.Gp, p.sb, s);
+      if (st) return st;
+    }
   }
-  hipLaunchKernelGGL(sum_slabs_kernel, dim3(ew_grid(BH)), dim3(kBlock), 0, s, (const float*)slabs, p.sb, p.bwd_slab, dh0, BH);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3(ew_grid(BH)), dim3(kBlock), 0, s, (const float*)slabs, p.sb, BH, dh0, BH);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

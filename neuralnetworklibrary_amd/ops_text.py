@@ -32,7 +32,7 @@ class _LSTMRecurrence(torch.autograd.Function):
         y = torch.empty(T, B, H, dtype=torch.float32, device=dev)
         cy = torch.empty(T, B, H, dtype=torch.float32, device=dev)
         gates = torch.empty(T, B, G, dtype=torch.float32, device=dev)
-        wsb = int(lib.nnl_lstm_workspace_bytes(B, H))
+        wsb = int(lib.nnl_lstm_workspace_bytes(T, B, H))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
         check(lib.nnl_lstm_fwd(ptr(gx), ptr(w_pad), ptr(h0), ptr(c0), ptr(y), ptr(cy), ptr(gates), T, B, H, ptr(ws), wsb, stream()))
         ctx.save_for_backward(w_hh, h0, c0, y, cy, gates)
@@ -55,7 +55,7 @@ class _LSTMRecurrence(torch.autograd.Function):
         dgates = torch.zeros(T, B, Gp, dtype=torch.float32, device=dev)        # pad columns must be zero
         dh0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
-        wsb = int(lib.nnl_lstm_workspace_bytes(B, H))
+        wsb = int(lib.nnl_lstm_workspace_bytes(T, B, H))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
         check(lib.nnl_lstm_bwd(ptr(dy), ptr(dhT), ptr(dcT), ptr(gates), ptr(cy), ptr(c0), ptr(w_t), ptr(dgates), ptr(dh0),
                                ptr(dc0), T, B, H, ptr(ws), wsb, stream()))

@@ -205,3 +205,37 @@ def test_embedding_rowmask_bit_exact_and_grad():
     assert_close(o, ref, 1e-6, 1e-7, 'out')
     assert_close(Wg.grad, Wc.grad, 1e-4, 1e-5, 'dW')
     assert float(Wg.grad[1].abs().sum()) == 0.0                            # padding row gets no gradient
+
+
+@pytest.mark.gpu
+def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable():
+    """BASELINE-size layer (bs 64, bptt 70, 1150 -> 1150): the fused step kernel hands split-K partial tiles between
+    workgroups (ticket + device-scope stores / loads, 72 tiles x 70 steps per pass); a stale hand-over would show up as a
+    run-to-run difference or a large error.  Checked bitwise over repeated runs and against torch's LSTM in fp64."""
+    from neuralnetworklibrary_amd import ops_text
+    T, B, I, H = 70, 64, 1150, 1150
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(T, B, I, generator=g) * 0.5)
+    w_ih, w_hh = torch.randn(4 * H, I, generator=g) / I ** 0.5, torch.randn(4 * H, H, generator=g) / H ** 0.5
+    b_ih, b_hh = torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1
+    h0, c0 = torch.randn(1, B, H, generator=g) * 0.1, torch.randn(1, B, H, generator=g) * 0.1
+    dev = lambda t: t.to('cuda')
+    runs = []
+    for _ in range(3):
+        xg, wg = dev(x).requires_grad_(True), dev(w_hh).requires_grad_(True)
+        y, (hT, cT) = ops_text.lstm_layer(xg, dev(h0), dev(c0), dev(w_ih), wg, dev(b_ih), dev(b_hh))
+        (y.sum() + 0.5 * cT.sum()).backward()
+        runs.append((y.detach().clone(), cT.detach().clone(), xg.grad.clone(), wg.grad.clone()))
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b), 'LSTM forward / backward must be bitwise repeatable'
+    ref = torch.nn.LSTM(I, H).double()
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(w_ih); ref.weight_hh_l0.copy_(w_hh); ref.bias_ih_l0.copy_(b_ih); ref.bias_hh_l0.copy_(b_hh)
+    xd = x.double().requires_grad_(True)
+    yd, (hd, cd) = ref(xd, (h0.double(), c0.double()))
+    (yd.sum() + 0.5 * cd.sum()).backward()
+    assert_close(runs[0][0], yd.detach(), 1e-4, 1e-5, 'y')
+    assert_close(runs[0][1], cd.detach(), 1e-4, 1e-5, 'cT')
+    assert_close(runs[0][2], xd.grad, 1e-3, 1e-4 * xd.grad.abs().max().item(), 'dx')
+    assert_close(runs[0][3], ref.weight_hh_l0.grad, 1e-3, 1e-4 * ref.weight_hh_l0.grad.abs().max().item(), 'dW_hh')
