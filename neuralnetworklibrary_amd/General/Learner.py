@@ -97,14 +97,26 @@ class _GraphedStep:
     """One captured training step for one input signature (Learner.use_graphs)."""
 
     def __init__(self, warmup):
-        self.left, self.graph, self.x, self.y, self.loss = warmup, None, None, None, None
+        self.left, self.graph, self.x, self.y, self.loss = max(int(warmup), 1), None, None, None, None
+        self.stream = None
 
     def run(self, learner, x_batch, y_batch):
         opt = learner.optimizer
         if self.graph is None:
-            if self.left > 0:                         # eager steps first: lazy state (optimizer moments, gather plans,
+            if self.left > 1:                         # eager steps first: lazy state (optimizer moments, gather plans,
                 self.left -= 1                        # workspaces) must exist before the capture
                 return None
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+            if self.left == 1:
+                # the last eager step runs on the capture stream, as torch's whole-network capture recipe asks: the
+                # parameters' AccumulateGrad nodes then belong to the stream the graph will be recorded on
+                self.left = 0
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    loss = learner._eager_step(x_batch, y_batch)
+                torch.cuda.current_stream().wait_stream(self.stream)
+                return loss
             dev = default_device()
             self.x = _tree_map(lambda t: t.detach().to(dev, copy=True), x_batch)
             self.y = _tree_map(lambda t: t.detach().to(dev, copy=True), y_batch)
@@ -114,7 +126,7 @@ class _GraphedStep:
             opt.prepare_capture()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):             # records; nothing executes until replay()
+            with torch.cuda.graph(graph, stream=self.stream):      # records; nothing executes until replay()
                 y_pred = learner.predict1minibatch(self.x)
                 self.loss = learner.loss_func(y_pred, self.y)
                 self.loss.backward()
@@ -429,6 +441,11 @@ class Learner(object):
             loss = self._graphed_step(x_batch, y_batch)
             if loss is not None:
                 return loss
+        return self._eager_step(x_batch, y_batch)
+
+    def _eager_step(self, x_batch, y_batch):
+        "zero_grad -> forward -> loss -> backward -> Optimizer.step -> loss.item()  (General/Learner.py:506-516)"
+        opt = self.optimizer
         opt.opt.zero_grad()
         if self.grad_sync is not None:
             self.grad_sync.begin()
