@@ -39,7 +39,21 @@ end_metrics = {'auc': AUC}
 SGD_Mom = partial(optim.SGD, momentum=0.9)
 Adam2 = partial(optim.Adam, betas=(0.9, 0.99))
 opt_dict = {'default': SGD_Mom, 'SGD_Mom': SGD_Mom, 'SGD': optim.SGD, 'Adam': optim.Adam, 'Adam2': Adam2}
-loss_func_dict = {'cont': nn.MSELoss(), 'cat': nn.CrossEntropyLoss(), 'single_label': nn.CrossEntropyLoss(),
+class HipCrossEntropyLoss(nn.CrossEntropyLoss):
+    """nn.CrossEntropyLoss() (the default loss of the 'cat' / 'single_label' target types, reference General/Learner.py:20)
+    on the online-softmax HIP kernels (csrc/text.hip: one pass for max and sum-exp, one for the gradient) when the inputs are
+    CUDA class-index targets with the default options; anything else (CPU tensors in host-logic tests, class weights, label
+    smoothing, probability targets) takes torch's implementation."""
+
+    def forward(self, input, target):
+        plain = (self.weight is None and self.reduction == 'mean' and self.ignore_index == -100 and self.label_smoothing == 0.0)
+        if plain and input.is_cuda and input.dim() >= 2 and target.dtype == torch.long and target.dim() == input.dim() - 1:
+            from ..ops_text import cross_entropy_nd
+            return cross_entropy_nd(input, target)
+        return super().forward(input, target)
+
+
+loss_func_dict = {'cont': nn.MSELoss(), 'cat': HipCrossEntropyLoss(), 'single_label': HipCrossEntropyLoss(),
                   'multi_label': nn.BCEWithLogitsLoss()}
 
 
