@@ -80,6 +80,9 @@ def cpu_baseline(bs, sz, steps=2):
             'ms_per_step': dt * 1e3}
 
 
+FLOP_KINDS = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'gemm', 'lstm')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -165,8 +168,10 @@ def main():
                 'avg_launch_ms': conv_ms / max(conv_launches, 1),
                 'flop_per_launch': conv_flop / max(conv_launches, 1),
                 'conv_ms_per_step': conv_ms / max(n_prof, 1),
+                # per C-entry-point family: algorithmic FLOPs (conv / gemm / lstm) or algorithmic BYTES (the HBM-bound kinds)
                 'by_kind': {k: {'ms_per_step': round(v['ms'] / max(n_prof, 1), 3),
-                                'tflops': round(v['work'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None}
+                                ('tflops' if k in FLOP_KINDS else 'tbytes_per_s'):
+                                    round(v['work'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None}
                             for k, v in prof.items() if v['launches']}}
 
     if rank == 0:
