@@ -208,11 +208,13 @@ def test_embedding_rowmask_bit_exact_and_grad():
 
 
 @pytest.mark.gpu
-def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable():
+@pytest.mark.parametrize('fused_bwd', ['0', '1'])
+def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, monkeypatch):
     """BASELINE-size layer (bs 64, bptt 70, 1150 -> 1150): the fused step kernel hands split-K partial tiles between
     workgroups (ticket + device-scope stores / loads, 72 tiles x 70 steps per pass); a stale hand-over would show up as a
     run-to-run difference or a large error.  Checked bitwise over repeated runs and against torch's LSTM in fp64."""
     from neuralnetworklibrary_amd import ops_text
+    monkeypatch.setenv('NNL_LSTM_FUSED_BWD', fused_bwd)       # '1': the (slower) fused backward step is kept tested too
     T, B, I, H = 70, 64, 1150, 1150
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(T, B, I, generator=g) * 0.5)
