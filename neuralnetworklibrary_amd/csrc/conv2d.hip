@@ -72,20 +72,23 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
 struct BalPlan {
   int on, bk, main_ks, n_main_tiles, tail_slices, tail_row0;
   size_t main_floats, tail_floats;        // workspace: [main slabs][tail slabs]
+  int bm;                                 // tile rows: 64 (64x64 tile) or 128 (128x64 tile, BK 16)
+  double t_us;                            // predicted time of the chosen plan
 };
 
 constexpr int kCUs = 256;
 
-BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
+BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   BalPlan best{};
+  best.bm = bm;
   const char* e = getenv("NNL_IGEMM_BALANCE");
   if ((e && atoi(e) == 0) || Nc % 4 != 0) return best;
-  const long gm = nnl_cdiv(M, 64), gn = nnl_cdiv(Nc, 64), T = gm * gn;
+  const long gm = nnl_cdiv(M, bm), gn = nnl_cdiv(Nc, 64), T = gm * gn;
   const char* e_bk = getenv("NNL_IGEMM_BK32");
-  const int bk = ((e_bk ? atoi(e_bk) : (T < 1200)) && C % 32 == 0) ? 32 : 16;
+  const int bk = (bm == 64 && (e_bk ? atoi(e_bk) : (T < 1200)) && C % 32 == 0) ? 32 : 16;
   const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
-  const double c_it = bk == 32 ? 0.60 : 0.30;                          // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
-  const double occ = bk == 32 ? 4 : 6;                                 // resident workgroups per CU (LDS- / VGPR-limited)
+  const double c_it = (bk == 32 ? 0.60 : 0.30) * (bm / 64);            // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
+  const double occ = bm == 128 ? 5 : (bk == 32 ? 4 : 6);               // resident workgroups per CU (LDS- / VGPR-limited)
   auto wave_iters = [&](long blocks, long iters) {                     // busiest CU's iterations for `blocks` equal workgroups
     if (blocks <= 0) return 0.0;
     const long cap = (long)occ * kCUs;                                 // full residency waves, then the remainder on top
@@ -93,6 +96,7 @@ BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
     return (double)(full * (long)occ + nnl_cdiv(rem, kCUs)) * iters;
   };
   const double plain = wave_iters(T, I) * c_it;
+  best.t_us = plain;
   double best_t = plain * ((e && atoi(e) == 2) ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
   for (int ks = 1; ks <= 4; ks *= 2) {
     if (I / ks < 8) break;
@@ -107,12 +111,13 @@ BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
       const long it_tail = nnl_cdiv(I, S);
       const long tail_blocks = tail * S;
       double t = (wave_iters(n_main * ks, it_main) + wave_iters(tail_blocks, it_tail + (S > 1 ? 2 : 0))) * c_it;
-      const long row0 = (n_main / gn) * 64 < M ? (n_main / gn) * 64 : M;
+      const long row0 = (n_main / gn) * bm < M ? (n_main / gn) * bm : M;
       const double main_b = ks > 1 ? (2.0 * ks + 1) * row0 * Nc * 4 : 0;
       const double tail_b = S > 1 ? (2.0 * S + 1) * (M - row0) * Nc * 4 : 0;
       t += (main_b + tail_b) / 4.0e6 + (ks > 1 ? 1 : 0) + (S > 1 && tail ? 1 : 0);      // reduce traffic at ~4 TB/s + launch gap
       if (t < best_t) {
         best_t = t;
+        best.t_us = t;
         best.on = 1; best.bk = bk; best.main_ks = ks; best.n_main_tiles = (int)n_main; best.tail_slices = tail ? S : 1;
         best.tail_row0 = (int)row0;
         best.main_floats = ks > 1 ? (size_t)ks * row0 * Nc : 0;
@@ -122,6 +127,16 @@ BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
   }
   if (best.on && best.main_ks == 1 && best.tail_slices == 1) best.on = 0;
   return best;
+}
+
+BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
+  BalPlan p64 = plan_balance_tile(M, Nc, C, ntaps, 64);
+  const char* e = getenv("NNL_IGEMM_BM128");                           // experiment: also consider the 128x64 tile
+  if (e && atoi(e) >= 1 && M >= 4096) {
+    BalPlan p128 = plan_balance_tile(M, Nc, C, ntaps, 128);
+    if (p128.on && (p128.t_us < p64.t_us || atoi(e) == 2)) return p128;
+  }
+  return p64;
 }
 
 size_t balance_workspace_bytes(long M, int Nc, int C, int ntaps) {
@@ -145,14 +160,16 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t s) {
   { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
-  p.grid_m = (int)nnl_cdiv(p.M, 64);
+  p.grid_m = (int)nnl_cdiv(p.M, pl.bm);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
   const int T = p.grid_m * p.grid_n;
   p.bal = 1; p.main_ks = pl.main_ks; p.n_main_tiles = pl.n_main_tiles; p.tail_slices = pl.tail_slices; p.tail_row0 = pl.tail_row0;
   p.main_out = ws; p.main_slab_stride = (long)pl.tail_row0 * p.Nc;
   p.tail_out = ws + pl.main_floats; p.tail_slab_stride = (long)(p.M - pl.tail_row0) * p.Nc;
   const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
-  if (pl.bk == 32 && p.variant == 1)
+  if (pl.bm == 128)
+    hipLaunchKernelGGL((igemm_taps_kernel<128, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk == 32 && p.variant == 1)
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk == 32)
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2>), dim3(grid), dim3(256), 0, s, p);
