@@ -554,7 +554,55 @@ def g11_bbox_inference():
     save('g11_bbox_inference', **out)
 
 
-GROUPS = {'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
+def g12_objectdetectionnet():
+    """G12: the reference's ObjectDetectionNet (ResNet-50 Bottleneck body + FPN + re-initialised heads, Vision.py:1382-1471) on
+    x [2,3,64,64], K=3: reg / clas activations, SSD_loss (0.5, 0.25, 2.0) and per-parameter gradient norms, in fp32 AND fp64,
+    with BatchNorm in training mode (fp32-vs-fp64 gap criterion, as G6) and in eval mode (well conditioned: also gradient
+    slices).  The constructor's `vmods.retinanet.retinanet()` loads a COCO checkpoint that is an LFS pointer in the snapshot
+    (retinanet.py:430-435): it is replaced HERE by the same architecture with seeded weights (synth.fill_module_)."""
+    RN = R['Applications.VisionModels.retinanet']
+    V = R['Applications.Vision']
+    RN.retinanet = lambda *a, **k: RN.RetinaNet(80, RN.Bottleneck, [3, 4, 6, 3])
+    N, S, K = 2, 64, 3
+    x = synth.synth_input((N, 3, S, S), 12)
+    boxes = -np.ones((N, 2, 4), np.float32); cats = -np.ones((N, 2), np.int64)
+    boxes[0] = [[4, 6, 40, 44], [20, 10, 60, 34]]; cats[0] = [2, 0]
+    boxes[1, 0] = [8, 30, 50, 62]; cats[1, 0] = 1
+    B, Cc = torch.from_numpy(boxes), torch.from_numpy(cats)
+    out = {'N': N, 'S': S, 'K': K, 'boxes': boxes, 'cats': cats}
+    slices = ['layer0.0.weight', 'layer2.0.conv2.weight', 'fpn.P5_1.weight', 'fpn.P3_2.weight', 'classifier.conv1.weight',
+              'classifier.output.bias', 'regressor.output.weight']
+    for tag, dtype in [('f32', torch.float32), ('f64', torch.float64)]:
+        torch.manual_seed(0)
+        net = V.ObjectDetectionNet(K)
+        synth.fill_module_(net)
+        net = net.to(dtype)
+        sd = dict(net.named_parameters())
+        if tag == 'f32':
+            out['param_names'] = np.array([n for n, _ in net.named_parameters()])
+            out['slice_names'] = np.array([n for n in slices if n in sd])
+        for mode in ['train', 'eval']:
+            net.train() if mode == 'train' else net.eval()
+            for p in net.parameters():
+                p.grad = None
+            anchors, reg, clas = net(x.to(dtype))
+            lf = V.SSD_loss(0.5, 0.25, 2.0)
+            loss = lf([anchors, reg, clas], [B.to(dtype), Cc])
+            loss.backward()
+            pre = '%s.' % mode
+            out[pre + 'reg.' + tag], out[pre + 'clas.' + tag] = A(reg).astype(np.float64), A(clas).astype(np.float64)
+            out[pre + 'loss.' + tag] = A(loss).astype(np.float64).reshape(1)
+            out[pre + 'grad_norms.' + tag] = np.array([0.0 if p.grad is None else p.grad.norm().item() for _, p in net.named_parameters()], dtype=np.float64)
+            if mode == 'eval':
+                for n in slices:
+                    if n in sd and sd[n].grad is not None:
+                        out['eval.grad.%s.%s' % (n, tag)] = A(sd[n].grad).reshape(-1)[:1024].astype(np.float64)
+        if tag == 'f32':
+            out['anchors.shape'] = np.array(A(anchors).shape)
+    save('g12_objectdetectionnet', **out)
+
+
+GROUPS = {'g12': g12_objectdetectionnet, 'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)
