@@ -602,7 +602,74 @@ def g12_objectdetectionnet():
     save('g12_objectdetectionnet', **out)
 
 
-GROUPS = {'g12': g12_objectdetectionnet, 'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
+def g4_fcnet_and_g10_fit_curves():
+    """G4: FullyConnectedNet([20,16,8,3], drops [.3,.2,.1], pre_bn) with every nn.Dropout replaced by pre-drawn masks: forward,
+    loss, all gradients, BN running stats (batch 12).  G10: 20-step loss curves of the reference Learner.fit (2 epochs x 10
+    minibatches) on seeded synthetic data objects — CollabFilterNet (n_user 30, n_item 20, D 6; Adam, wd 1e-4) and
+    StructuredDataNet (cards [7,5,4], 3 continuous, fc [16,8,1], dropout 0; Adam, wd 1e-3) — plus the pre-training and final
+    validation losses."""
+    L = R['General.Layers']
+    CF = R['Applications.CollabFiltering']
+    SD = R['Applications.StructuredData']
+    out = {}
+    # ---- G4
+    net = L.FullyConnectedNet([20, 16, 8, 3], [0.3, 0.2, 0.1])
+    synth.fill_module_(net, seed=14)
+    masks = [_mask((12, 20), 0.3, 141), _mask((12, 16), 0.2, 142), _mask((12, 8), 0.1, 143)]
+    net.lins[0].drop, net.lins[1].drop, net.final_drop = _FixedDrop([masks[0]]), _FixedDrop([masks[1]]), _FixedDrop([masks[2]])
+    net.train()
+    x = synth.synth_input((12, 20), 144).requires_grad_(True)
+    y = torch.arange(12) % 3
+    logits = net(x)
+    loss = torch.nn.CrossEntropyLoss()(logits, y)
+    loss.backward()
+    out.update({'g4.mask0': A(masks[0]), 'g4.mask1': A(masks[1]), 'g4.mask2': A(masks[2]), 'g4.logits': A(logits), 'g4.loss': A(loss),
+                'g4.dx': A(x.grad), 'g4.param_names': np.array([n for n, _ in net.named_parameters()])})
+    for n, p in net.named_parameters():
+        out['g4.grad.' + n] = A(p.grad)
+    for n, b in net.named_buffers():
+        out['g4.buf.' + n] = A(b)
+    # ---- G10 collab
+    rs = np.random.RandomState(100)
+    def collab_batches(n):
+        return [(torch.from_numpy(np.stack([rs.randint(0, 30, 16), rs.randint(0, 20, 16)], 1)),
+                 torch.from_numpy(rs.randint(1, 6, 16).astype(np.float32))) for _ in range(n)]
+    tr, va = collab_batches(10), collab_batches(3)
+    net = CF.CollabFilterNet(30, 20, 6, [0.8, 5.2])
+    synth.fill_module_(net, seed=15)
+    learner = Learner('/tmp/nnl_golden_g10', FakeData(tr, va, 16, 'cont'), net, optimizer='Adam')
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        pre = learner.evaluate('val')[0]
+        learner.fit(2e-2, 2, wd=1e-4)
+        post = learner.evaluate('val')[0]
+    out.update({'g10.collab.loss_sched': np.array(learner.loss_sched, dtype=np.float64), 'g10.collab.val_pre': np.array([pre]),
+                'g10.collab.val_post': np.array([post])})
+    for i, (xb, yb) in enumerate(tr + va):
+        out['g10.collab.x%d' % i], out['g10.collab.y%d' % i] = A(xb), A(yb)
+    # ---- G10 tabular
+    cards = [7, 5, 4]
+    def tab_batches(n):
+        return [([torch.from_numpy(np.stack([rs.randint(0, c, 16) for c in cards], 1)),
+                  torch.from_numpy(rs.standard_normal((16, 3)).astype(np.float32))],
+                 torch.from_numpy((5 + 7 * rs.rand(16)).astype(np.float32))) for _ in range(n)]
+    tr, va = tab_batches(10), tab_batches(3)
+    labels = [{i: i for i in range(c)} for c in cards]
+    net = SD.StructuredDataNet('cont', 3, 3, labels, [16, 8, 1], output_range=[5, 12])
+    synth.fill_module_(net, seed=16)
+    learner = Learner('/tmp/nnl_golden_g10', FakeData(tr, va, 16, 'cont'), net, optimizer='Adam')
+    with contextlib.redirect_stdout(io.StringIO()):
+        pre = learner.evaluate('val')[0]
+        learner.fit([1e-2, 2e-2], 2, wd=1e-3)
+        post = learner.evaluate('val')[0]
+    out.update({'g10.tab.loss_sched': np.array(learner.loss_sched, dtype=np.float64), 'g10.tab.val_pre': np.array([pre]),
+                'g10.tab.val_post': np.array([post]), 'g10.tab.emb_dims': np.array([e.emb.weight.shape[1] for e in net.embeddings])})
+    for i, ((xc, xf), yb) in enumerate(tr + va):
+        out['g10.tab.xcat%d' % i], out['g10.tab.xcont%d' % i], out['g10.tab.y%d' % i] = A(xc), A(xf), A(yb)
+    save('g4_g10_fcnet_fit', **out)
+
+
+GROUPS = {'g4': g4_fcnet_and_g10_fit_curves, 'g12': g12_objectdetectionnet, 'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)
