@@ -85,8 +85,13 @@ typedef struct {
  * when the tile grid is not a multiple of the 256 CUs, the last tiles (or all of them) are cut into k slices whose
  * partial slabs are summed in a fixed order (bitwise reproducible run to run). */
 size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g);
+/* tile_counters (optional): a PERSISTENT device array of nnl_conv2d_tile_counters() int32, zero-initialised once by the
+ * caller and never touched otherwise (one per device and stream).  With it the last k slice of a split tile to finish sums
+ * the slabs in slice order and writes the output inside the conv kernel (no separate reduce launch); each counter returns
+ * to zero before the kernel ends.  NULL: the slabs are reduced by a second launch. */
+int64_t nnl_conv2d_tile_counters(void);
 int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
-                   int relu, void* workspace, size_t workspace_bytes, void* stream);
+                   int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream);
 /* wt[C,R,S,K] = transpose of w[K,R,S,C] over (K,C): the B operand of dgrad. */
 int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
 /* dx[N,H,W,C] = sum_{r,s,k} dy[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * wt[c,r,s,k] (integral taps only). */
@@ -95,7 +100,7 @@ size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g);   /* optional
  * input through the identity shortcut of BasicBlock / Bottleneck (retinanet.py:43-59) is added in the epilogue instead of
  * by a separate autograd accumulation kernel. */
 int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
  * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */
 size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g);

@@ -112,25 +112,13 @@ class _GraphedStep:
 
     def __init__(self, warmup):
         self.left, self.graph, self.x, self.y, self.loss = max(int(warmup), 1), None, None, None, None
-        self.stream = None
 
     def run(self, learner, x_batch, y_batch):
         opt = learner.optimizer
         if self.graph is None:
-            if self.left > 1:                         # eager steps first: lazy state (optimizer moments, gather plans,
+            if self.left > 0:                         # eager steps first: lazy state (optimizer moments, gather plans,
                 self.left -= 1                        # workspaces) must exist before the capture
                 return None
-            if self.stream is None:
-                self.stream = torch.cuda.Stream()
-            if self.left == 1:
-                # the last eager step runs on the capture stream, as torch's whole-network capture recipe asks: the
-                # parameters' AccumulateGrad nodes then belong to the stream the graph will be recorded on
-                self.left = 0
-                self.stream.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.stream):
-                    loss = learner._eager_step(x_batch, y_batch)
-                torch.cuda.current_stream().wait_stream(self.stream)
-                return loss
             dev = default_device()
             self.x = _tree_map(lambda t: t.detach().to(dev, copy=True), x_batch)
             self.y = _tree_map(lambda t: t.detach().to(dev, copy=True), y_batch)
@@ -140,7 +128,7 @@ class _GraphedStep:
             opt.prepare_capture()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=self.stream):      # records; nothing executes until replay()
+            with torch.cuda.graph(graph):             # records; nothing executes until replay()
                 y_pred = learner.predict1minibatch(self.x)
                 self.loss = learner.loss_func(y_pred, self.y)
                 self.loss.backward()

@@ -77,6 +77,7 @@ struct BalPlan {
 };
 
 constexpr int kCUs = 256;
+constexpr long kTileCounters = 65536;   // ints in the caller's persistent tile-counter buffer (nnl_conv2d_tile_counters())
 
 BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   BalPlan best{};
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   reinterpret_cast<f32x4*>(out)[i] = acc;
 }
 
-int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t s) {
+int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counters, hipStream_t s) {
   { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
   p.grid_m = (int)nnl_cdiv(p.M, pl.bm);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
@@ -166,6 +167,7 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t
   p.bal = 1; p.main_ks = pl.main_ks; p.n_main_tiles = pl.n_main_tiles; p.tail_slices = pl.tail_slices; p.tail_row0 = pl.tail_row0;
   p.main_out = ws; p.main_slab_stride = (long)pl.tail_row0 * p.Nc;
   p.tail_out = ws + pl.main_floats; p.tail_slab_stride = (long)(p.M - pl.tail_row0) * p.Nc;
+  p.tile_counters = (pl.bm == 64) ? counters : nullptr;      // in-kernel fix-up of the split tiles (64x64 tile only)
   const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
   if (pl.bm == 128)
     hipLaunchKernelGGL((igemm_taps_kernel<128, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
@@ -178,6 +180,7 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t
   else
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();
+  if (p.tile_counters != nullptr) return NNL_OK;             // the kernel reduced its own slabs
   const int Nc4 = p.Nc / 4;
   if (pl.main_ks > 1 && pl.tail_row0 > 0) {
     const long n4 = (long)pl.tail_row0 * Nc4;
@@ -197,7 +200,7 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, hipStream_t
 
 // Tile choice: estimated time = rounds of resident workgroups x per-workgroup work / per-tile MFMA efficiency.
 // Resident workgroups per CU (VGPR/LDS limited) and efficiencies are measured values (tools/bench_conv.py).
-int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0) {
+int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0, int* counters = nullptr) {
   const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
@@ -226,7 +229,10 @@ int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, s
       const bool dense_out = p.out_stride == 1 && p.OH == p.P && p.OW == p.Q && p.oh0 == 0 && p.ow0 == 0 && p.ksplit <= 1;
       if (ws != nullptr && dense_out) {
         const BalPlan pl = plan_balance(p.M, p.Nc, p.C, p.ntaps);
-        if (pl.on && ws_bytes >= (pl.main_floats + pl.tail_floats) * sizeof(float)) return launch_balanced(p, pl, (float*)ws, s);
+        if (pl.on && ws_bytes >= (pl.main_floats + pl.tail_floats) * sizeof(float)) {
+          const long tiles = nnl_cdiv(p.M, pl.bm) * nnl_cdiv(p.Nc, 64);
+          return launch_balanced(p, pl, (float*)ws, tiles <= kTileCounters ? counters : nullptr, s);
+        }
       }
       // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
@@ -497,8 +503,10 @@ extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
   return balance_workspace_bytes((long)g->N * g->H * g->W, g->C, g->K, g->R * g->S);
 }
 
+extern "C" int64_t nnl_conv2d_tile_counters(void) { return kTileCounters; }
+
 extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
-                              int relu, void* workspace, size_t workspace_bytes, void* stream) {
+                              int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream) {
   int st = check_geom(g, "conv2d_fwd");
   if (st) return st;
   NNL_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
@@ -525,7 +533,7 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
         q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
         q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
       }
-    return dispatch_taps(q, s, workspace, workspace_bytes);
+    return dispatch_taps(q, s, workspace, workspace_bytes, tile_counters);
   }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
 }
@@ -541,7 +549,7 @@ extern "C" int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int
 }
 
 extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream) {
   int st = check_geom(g, "conv2d_dgrad");
   if (st) return st;
   NNL_CHECK_ARG(dy && wt && dx, "conv2d_dgrad: null pointer");
@@ -594,7 +602,7 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
           if (c.M <= 0) continue;
           if (nt == 0) { need_zero = true; continue; }
           if (pass == 0) continue;                      // first pass only finds out whether dx needs a zero fill
-          int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes);
+          int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes, tile_counters);
           if (st) return st;
         }
     }

@@ -64,6 +64,9 @@ struct IgemmTapsParams {
   int variant;                         // 1: PIPE instantiation of the 64x64 kernel (A/B: tools/bench_conv.py --ab NNL_IGEMM_VARIANT=0,1)
   float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
   float* tail_out; long tail_slab_stride;      // tail_slices > 1: slabs [tail_slices][M - tail_row0][Nc]
+  int* tile_counters;                          // != null: the last k slice of a tile to finish (atomic ticket) sums the slabs in
+                                               // slice order and writes the output itself — no separate reduce launch.  One int
+                                               // per tile, ZERO at rest (the finishing workgroup resets it)
   int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
   int tap_woff[IGEMM_MAX_TAPS];        // offset of the tap's C weights inside a B row, elements
   signed char tap_dh[IGEMM_MAX_TAPS], tap_dw[IGEMM_MAX_TAPS];
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   int logical, kslice = 0, nslices = 1, row0 = 0;
+  bool in_tail = false;
   float* yout = p.y;
   if (p.bal) {
     const int nmb = p.n_main_tiles * p.main_ks;
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       kslice = tb - t * p.tail_slices;
       logical = p.n_main_tiles + t;
       nslices = p.tail_slices;
-      if (nslices > 1) { yout = p.tail_out + (long)kslice * p.tail_slab_stride; row0 = p.tail_row0; }
+      if (nslices > 1) { yout = p.tail_out + (long)kslice * p.tail_slab_stride; row0 = p.tail_row0; in_tail = true; }
     }
   } else {
     logical = nnl_xcd_remap(blockIdx.x, gridDim.x);
@@ -389,6 +393,49 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   }
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
+  if (EPI == 0 && BM == 64 && BN == 64 && p.bal && partial && p.tile_counters != nullptr) {
+    // ---- in-kernel fix-up of a split tile (same hand-over as the fused LSTM step: sc1 stores, drain, ticket, sc1 loads) ----
+    __shared__ int ticket;
+    float* const base = in_tail ? p.tail_out : p.main_out;
+    const long sstride = in_tail ? p.tail_slab_stride : p.main_slab_stride;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)((long)nslices * sstride * 4), 0x00020000);
+    constexpr int kSc1 = 1 << 4;
+    const int cl = n0 + wn * 32 + col_l;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+      const long off = (long)kslice * sstride + (long)(row - row0) * p.Nc + cl;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[0][0][e]), rs, (row < p.M && cl < p.Nc) ? (int)(off * 4) : -1, 0, kSc1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ticket = __hip_atomic_fetch_add(&p.tile_counters[logical], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != nslices - 1) return;
+    if (tid == 0) __hip_atomic_store(&p.tile_counters[logical], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = n0 + (idx4 & 15) * 4;
+      const int row = m0 + rl;
+      if (row >= p.M || c4 >= p.Nc) continue;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      f32x4 part[8];
+      const int ns = nslices < 8 ? nslices : 8;
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl)
+        if (sl < ns) part[sl] = buf_load4_pol(rs, (unsigned)(((long)sl * sstride + (long)(row - row0) * p.Nc + c4) * 4), kSc1);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl)
+        if (sl < ns) v += part[sl];
+      for (int sl = 8; sl < nslices; ++sl)
+        v += buf_load4_pol(rs, (unsigned)(((long)sl * sstride + (long)(row - row0) * p.Nc + c4) * 4), kSc1);
+      const long o = (long)row * p.Nc + c4;
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
+      if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      *reinterpret_cast<f32x4*>(p.y + o) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WTN + j * 32 + col_l;

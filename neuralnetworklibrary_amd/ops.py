@@ -106,6 +106,24 @@ def _pad_c4(t_nhwc):
     return torch.nn.functional.pad(t_nhwc, (0, 4 - C % 4))
 
 
+_TILE_COUNTERS = {}
+
+
+def _tile_counters(device):
+    """persistent zero-at-rest ticket counters of the conv kernels' in-kernel split-tile fix-up (include/nnl.h), one buffer per
+    device: every op of this package runs on torch's current stream, one conv at a time (a captured step replays on that same
+    stream).  Created on first use outside stream capture (eager warm-up steps precede every capture)."""
+    import os
+    if os.environ.get('NNL_IGEMM_FIXUP', '1') == '0':
+        return None
+    t = _TILE_COUNTERS.get(device.index)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = _TILE_COUNTERS[device.index] = torch.zeros(int(lib.nnl_conv2d_tile_counters()), dtype=torch.int32, device=device)
+    return t
+
+
 class GradSlot:
     """Side channel between two autograd Functions of one residual block: the BN that closes the block parks the gradient of
     its identity shortcut here (instead of returning it to autograd) and the block's FIRST convolution adds it in the
@@ -136,7 +154,8 @@ class _Conv2d(torch.autograd.Function):
         b = None if bias is None else _f32c(bias)
         wsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g))         # balanced-schedule slabs (0 when the plain launch is used)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
-        check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, stream()))
+        check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
+                                 stream()))
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
         ctx.c_in = x.shape[1]
         ctx.save_for_backward(xn, wn, y if relu else None)
@@ -165,7 +184,8 @@ class _Conv2d(torch.autograd.Function):
             if ctx.slot is not None:
                 shortcut, ctx.slot.tensor = ctx.slot.tensor, None
             fuse = shortcut is not None and g.stride == 1 and g.K % 16 == 0 and shortcut.numel() == dxn.numel()
-            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb, stream()))
+            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
+                                       ptr(_tile_counters(dyn.device) if wsb else None), stream()))
             if shortcut is not None and not fuse:
                 dxn += shortcut.view_as(dxn)
             dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)

@@ -88,3 +88,35 @@ def test_graph_is_dropped_on_freeze_and_refused_with_grad_sync():
     assert len(learner._graphs) == 1
     learner._new_optimizer()
     assert learner._graphs == {}
+
+
+def test_resnet_classifier_graph_replay_trains_like_eager():
+    """A conv net with BatchNorm, pooling, the balanced conv schedule's in-kernel fix-up, the shortcut-gradient fusion and the
+    HIP cross-entropy: the replayed step must produce the SAME losses as the eager step (same kernels, same order)."""
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    N, S = 16, 64
+    g = torch.Generator().manual_seed(4)
+    batches = [(torch.randn(N, 3, S, S, generator=g).to(DEV), torch.randint(0, 2, (N,), generator=g).to(DEV)) for _ in range(3)]
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
+        train_dl = val_dl = batches
+
+    def run(graphs):
+        torch.manual_seed(0)
+        net = V.ImageClassificationNet(D, V.models.resnet18(), head=[[64], [0., 0.]])
+        learner = Learner('/tmp/nnl_graph_test', D, net, optimizer='SGD_Mom')
+        learner.init_optimizer(wd=1e-4)
+        if graphs:
+            learner.use_graphs(True, warmup=2)
+        net.train()
+        losses = [learner.train1minibatch(*batches[i % 3], [1e-3, 2e-3, 5e-3], mom_batch=0.9) for i in range(9)]
+        return np.array(losses), sum(gs.graph is not None for gs in learner._graphs.values())
+    le, _ = run(False)
+    lg, ng = run(True)
+    assert ng == 1
+    assert_close(lg, le, 1e-5, 1e-6, 'losses: graph replay vs eager')
