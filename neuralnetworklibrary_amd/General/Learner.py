@@ -160,6 +160,7 @@ class Learner(object):
         self.bn_frozen = None
         self.grad_sync = None
         self._graph_warmup, self._graphs = None, {}
+        self._loss_host, self._loss_event = None, None
 
     # ---- data parallelism (new) -----------------------------------------------------
     def distribute(self, bucket_mb=25.0, sync_bn=False):
@@ -446,15 +447,29 @@ class Learner(object):
         return self._eager_step(x_batch, y_batch)
 
     def _eager_step(self, x_batch, y_batch):
-        "zero_grad -> forward -> loss -> backward -> Optimizer.step -> loss.item()  (General/Learner.py:506-516)"
+        """zero_grad -> forward -> loss -> backward -> Optimizer.step -> the loss as a float (General/Learner.py:506-516).
+        The reference calls `loss.item()` last, which drains the GPU once per step.  Here the scalar starts its device->host
+        copy (pinned buffer + event) as soon as the forward has produced it, and the float is read after the backward and the
+        optimizer kernels have been LAUNCHED: the value is the same, but the host is already preparing the next minibatch while
+        the GPU finishes this one, so the device never idles between steps."""
         opt = self.optimizer
         opt.opt.zero_grad()
         if self.grad_sync is not None:
             self.grad_sync.begin()
         y_pred = self.predict1minibatch(x_batch)
         loss = self.loss_func(y_pred, y_batch)
+        early = loss.is_cuda and loss.numel() == 1 and not torch.cuda.is_current_stream_capturing()
+        if early:
+            if self._loss_host is None:
+                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                self._loss_event = torch.cuda.Event()
+            self._loss_host.copy_(loss.detach().reshape(()).float(), non_blocking=True)
+            self._loss_event.record()
         loss.backward()
         opt.step()
+        if early:
+            self._loss_event.synchronize()
+            return float(self._loss_host)
         return loss.item()
 
     def _graphed_step(self, x_batch, y_batch):
