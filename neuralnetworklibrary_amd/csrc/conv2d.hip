@@ -386,12 +386,16 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
   const char* e_bk = getenv("NNL_WGRAD_BK32");                       // tuning hook
   const int bk32 = e_bk ? atoi(e_bk) : 0;
+  const char* e_pipe = getenv("NNL_WGRAD_PIPE");                     // A/B hook: 1 = software-pipelined fragment reads
+  const int pipe = e_pipe ? atoi(e_pipe) : 1;
   if (pl.bm == 128 && pl.bn == 128) {
-    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);   // BK=32 measured -7 % here
+    if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2, true>), grid, block, 0, s, q);
+    else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);   // BK=32 measured -7 % here
   } else if (pl.bm == 128) {
     hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, q);
   } else {
     if (bk32 && pl.k_per_split % 32 == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2>), grid, block, 0, s, q);
+    else if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2, true>), grid, block, 0, s, q);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, q);
   }
   NNL_CHECK_LAUNCH();

@@ -21,7 +21,7 @@ struct IgemmWgradParams {
   float rcp_PQ, rcp_Q;
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN>
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgrad_kernel(const IgemmWgradParams p) {
   static_assert(WGM * WGN == 4, "4 waves per block");
   constexpr int CA = BM / 4, CB = BN / 4;
@@ -102,6 +102,32 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   auto compute = [&](int buf) {
     const float* As = lds[buf] + lh * BM + wm * WTM + l31;
     const float* Bs = lds[buf] + BK * BM + lh * BN + wn * WTN + l31;
+    if constexpr (PIPE) {
+      // software-pipelined: the fragment reads of k step kk+1 are issued before the MFMAs of step kk (a second, 4-register
+      // fragment set), so their LDS latency hides behind TM*TN MFMAs instead of being exposed at every step
+      float af[2][TM], bf[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[0][i] = As[i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[0][j] = Bs[j * 32];
+#pragma unroll
+      for (int kk = 0; kk < BK / 2; ++kk) {
+        const int c = kk & 1, n = c ^ 1;
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[n][i] = As[(kk + 1) * 2 * BM + i * 32];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bf[n][j] = Bs[(kk + 1) * 2 * BN + j * 32];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i], bf[c][j], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float af[TM], bf[TN];
