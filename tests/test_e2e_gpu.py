@@ -70,3 +70,48 @@ def test_tabular_fit_device_resident_with_graphs():
     after = learner.evaluate('val')[0]
     assert after < 0.25 * before, (before, after)
     assert len(learner.loss_sched) == 8 * len(data.train_dl)
+
+
+def test_image_classifier_workflow_freeze_unfreeze_findlr_save_load():
+    """The fast.ai-style workflow of the reference notebooks on the GPU path: train the head with the body frozen, find_lr,
+    unfreeze with per-layer-group learning rates, bn_freeze, checkpoint round trip with optimizer state, predict / evaluate."""
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    _setup()
+    N, S = 8, 64
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(4 * N, 3, S, S, generator=g)
+    ys = (xs.mean(dim=(1, 2, 3)) > 0).long()                       # a learnable rule
+    batches = [(xs[i * N:(i + 1) * N].to(DEV), ys[i * N:(i + 1) * N].to(DEV)) for i in range(4)]
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'neg', 1: 'pos'}, N, 'single_label'
+        train_dl, val_dl = batches, batches[:2]
+    torch.manual_seed(1)
+    net = V.ImageClassificationNet(D, V.models.resnet18(), head=[[32], [0.1, 0.1]])
+    learner = V.ImageLearner('/tmp/nnl_e2e_img', D, net, optimizer='SGD_Mom')
+    learner.freeze()
+    assert all(not p.requires_grad for p in net.body.parameters()) and all(p.requires_grad for p in net.head.parameters())
+    body0 = [p.detach().clone() for p in net.body.parameters()]
+    learner.fit(1e-2, 2, wd=1e-4)
+    assert all(torch.equal(a, b) for a, b in zip(body0, net.body.parameters())), 'frozen body must not move'
+    w_before = [p.detach().clone() for p in net.parameters()]
+    learner.find_lr(lr_min=1e-5, lr_max=1e-1, plot=False)
+    assert all(torch.equal(a, b) for a, b in zip(w_before, net.parameters())), 'find_lr must restore the weights'
+    learner.unfreeze()
+    learner.fit_one_cycle([1e-4, 3e-4, 3e-3], 2, wd=1e-4)
+    assert not all(torch.equal(a, b) for a, b in zip(body0, net.body.parameters()))
+    learner.bn_freeze('all')
+    learner.fit([1e-4, 3e-4, 1e-3], 1)
+    learner.bn_unfreeze()
+    learner.save('ckpt', save_optimizer=True)
+    before = learner.evaluate('val')
+    with torch.no_grad():
+        for p in net.parameters():
+            p.add_(0.05)
+    assert learner.evaluate('val')[0] != before[0]
+    learner.load('ckpt', saved_optimizer=True)
+    after = learner.evaluate('val')
+    assert after[0] == before[0] and after[1] == before[1]
+    probs, labels = learner.predict('val')
+    assert probs.shape == (2 * N, 2) and np.allclose(probs.sum(1), 1, atol=1e-5) and set(labels.tolist()) <= {0, 1}
+    learner.fit(1e-3, 1)                                            # training continues after a load
