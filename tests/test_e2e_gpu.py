@@ -115,3 +115,53 @@ def test_image_classifier_workflow_freeze_unfreeze_findlr_save_load():
     probs, labels = learner.predict('val')
     assert probs.shape == (2 * N, 2) and np.allclose(probs.sum(1), 1, atol=1e-5) and set(labels.tolist()) <= {0, 1}
     learner.fit(1e-3, 1)                                            # training continues after a load
+
+
+def test_detection_workflow_fit_predict_map():
+    "RetinaNet: a few SSD-loss training steps, then Learner.predict('val') through the GPU BBoxPredictor and compute_mAP."
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    _setup()
+    S, K = 128, 3
+    g = torch.Generator().manual_seed(0)
+
+    def target(n):
+        boxes = -torch.ones(n, 2, 4); cats = -torch.ones(n, 2, dtype=torch.long)
+        for i in range(n):
+            x0, y0 = torch.randint(0, 60, (2,), generator=g).tolist()
+            w, h = torch.randint(30, 60, (2,), generator=g).tolist()
+            boxes[i, 0] = torch.tensor([x0, y0, x0 + w, y0 + h], dtype=torch.float32)
+            cats[i, 0] = int(torch.randint(0, K, (1,), generator=g))
+        return boxes, cats
+    train = []
+    for _ in range(2):
+        b, c = target(2)
+        train.append((torch.randn(2, 3, S, S, generator=g).to(DEV), [b.to(DEV), c.to(DEV)]))
+    val = []
+    val_targets = []
+    for cats2 in ([0, 1], [2, 0]):                                       # every category has ground truth (else mAP1 is 0/0, as upstream)
+        b = torch.tensor([[[10., 12., 60., 70.], [50., 40., 100., 90.]]])
+        c = torch.tensor([cats2])
+        val.append((torch.randn(1, 3, S, S, generator=g).to(DEV), [b.to(DEV), c.to(DEV)]))
+        val_targets.append([(b[0, j].numpy(), int(c[0, j])) for j in range(2)])
+
+    class VDS:
+        images = [{'scale': 1.0}, {'scale': 0.5}]
+        y = val_targets
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b', 2: 'c'}, 2, 'bbox'
+        train_dl, val_dl, val_ds = train, val, VDS
+    torch.manual_seed(0)
+    net = V.ObjectDetectionNet(K)
+    learner = V.ImageLearner('/tmp/nnl_e2e_det', D, net, optimizer='SGD_Mom', loss_func=V.SSD_loss(0.5, 0.25, 2.0))
+    learner.fit(1e-3, 2, wd=1e-4)
+    assert len(learner.loss_sched) == 4 and all(np.isfinite(learner.loss_sched))
+    preds = learner.predict('val', thresh=0.0, max_boxes=5)              # thresh 0: an untrained net still returns boxes
+    assert len(preds) == 2
+    for (boxes, classes, scores), img in zip(preds, VDS.images):
+        assert 0 < len(boxes) <= 5 and len(boxes) == len(classes) == len(scores)
+        assert all(scores[i] >= scores[i + 1] for i in range(len(scores) - 1))
+        assert all(0 <= int(c) < K for c in classes)
+        assert np.all(np.array(boxes) <= S / img['scale'] + 1e-3)         # rescaled to the original image
+    m = learner.compute_mAP(predictions=preds, mAP_thresholds=[0.5])
+    assert 0.0 <= m <= 1.0
