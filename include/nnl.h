@@ -94,6 +94,16 @@ int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, 
                    int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream);
 /* wt[C,R,S,K] = transpose of w[K,R,S,C] over (K,C): the B operand of dgrad. */
 int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
+/* The same transpose for MANY filters in one launch (all convolutions of a model, once per backward pass instead of one small
+ * launch per layer).  desc: DEVICE array, one entry per filter; tile_tensor: DEVICE int32 [n_tiles], the entry each 32x32 tile
+ * belongs to (entry i owns tiles [first_tile, first_tile + R*S*ceil(K/32)*ceil(C/32))). */
+typedef struct {
+  const float* w;   /* [K,RS,C] */
+  float* wt;        /* [C,RS,K] */
+  int32_t K, RS, C, first_tile;
+} nnl_wt_desc_t;
+int nnl_conv2d_weight_transpose_multi(const nnl_wt_desc_t* desc, const int32_t* tile_tensor, int64_t n_tiles,
+                                      double total_elems, void* stream);
 /* dx[N,H,W,C] = sum_{r,s,k} dy[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * wt[c,r,s,k] (integral taps only). */
 size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g);   /* optional workspace, as for the forward */
 /* addend (optional, [N,H,W,C], stride 1 and K % 16 == 0 only): dx = dgrad + addend — the gradient that reaches the block

@@ -29,6 +29,7 @@ class HipConv2d(nn.Conv2d):
     [K,C,R,S] shape but is STORED channels_last (= KRSC, the kernels' filter layout), so no per-step re-layout is needed
     and the weight gradient comes back in the parameter's own layout; state_dict load / save are unaffected."""
     fuse_relu = False
+    nnl_hip_conv = True               # ops.prepare_backward batches the filter transposes of these modules
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)

@@ -131,7 +131,7 @@ class _GraphedStep:
             with torch.cuda.graph(graph):             # records; nothing executes until replay()
                 y_pred = learner.predict1minibatch(self.x)
                 self.loss = learner.loss_func(y_pred, self.y)
-                self.loss.backward()
+                learner._backward(self.loss)
                 opt.step()
             self.graph, self.opt_capture = graph, opt.captured()
         else:
@@ -465,12 +465,24 @@ class Learner(object):
                 self._loss_event = torch.cuda.Event()
             self._loss_host.copy_(loss.detach().reshape(()).float(), non_blocking=True)
             self._loss_event.record()
-        loss.backward()
+        self._backward(loss)
         opt.step()
         if early:
             self._loss_event.synchronize()
             return float(self._loss_host)
         return loss.item()
+
+    def _backward(self, loss):
+        "loss.backward() with the per-pass preparation of the HIP layers (all conv filter transposes in one launch)"
+        if loss.is_cuda:
+            from .. import ops
+            ops.prepare_backward(self.model)
+            try:
+                loss.backward()
+            finally:
+                ops.finish_backward()
+        else:
+            loss.backward()
 
     def _graphed_step(self, x_batch, y_batch):
         "use_graphs(): replay (or first capture) the step for this input signature; None -> run it eagerly"

@@ -45,6 +45,7 @@ SIGNATURES = {
     'nnl_conv2d_tile_counters': (i64, []),
     'nnl_conv2d_fwd': (C.c_int, [c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), C.c_int, c_p, sz, c_p, c_p]),
     'nnl_conv2d_weight_transpose': (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p]),
+    'nnl_conv2d_weight_transpose_multi': (C.c_int, [c_p, c_p, i64, f64, c_p]),
     'nnl_conv2d_dgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, c_p, sz, c_p, c_p]),
     'nnl_conv2d_wgrad_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_wgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, sz, c_p]),

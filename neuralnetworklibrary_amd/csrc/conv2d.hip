@@ -266,6 +266,27 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
   }
 }
 
+// all conv filters of a model in ONE launch: descriptor d = {w, wt, K, RS, C, first tile}; blockIdx.x -> (tensor, tap, k tile, c tile)
+__global__ void weight_transpose_multi_kernel(const nnl_wt_desc_t* __restrict__ desc, const int* __restrict__ tile_tensor) {
+  __shared__ float tile[32][33];
+  const nnl_wt_desc_t d = desc[tile_tensor[blockIdx.x]];
+  int t = (int)blockIdx.x - d.first_tile;
+  const int ct = (d.C + 31) / 32, kt = (d.K + 31) / 32;
+  const int c0 = (t % ct) * 32; t /= ct;
+  const int k0 = (t % kt) * 32;
+  const int tap = t / kt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int k = k0 + i, c = c0 + tx;
+    tile[i][tx] = (k < d.K && c < d.C) ? d.w[((long)k * d.RS + tap) * d.C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, k = k0 + tx;
+    if (k < d.K && c < d.C) d.wt[((long)c * d.RS + tap) * d.K + k] = tile[tx][i];
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long n4,
                                                              int splits) {
   // out[i] = sum_s part[s][i] in a FIXED order (bitwise reproducible).  256 threads = 32 float4 columns x 8 split lanes:
@@ -548,6 +569,16 @@ extern "C" int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 8.0 * K * R * S * C);
   hipLaunchKernelGGL(weight_transpose_kernel, dim3((unsigned)nnl_cdiv(C, 32), (unsigned)nnl_cdiv(K, 32), R * S), dim3(256), 0, s, w,
                      wt, K, R * S, C);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_conv2d_weight_transpose_multi(const nnl_wt_desc_t* desc, const int32_t* tile_tensor, int64_t n_tiles,
+                                                 double total_elems, void* stream) {
+  NNL_CHECK_ARG(desc && tile_tensor && n_tiles > 0 && n_tiles < (1L << 31), "conv2d_weight_transpose_multi: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 8.0 * total_elems);
+  hipLaunchKernelGGL(weight_transpose_multi_kernel, dim3((unsigned)n_tiles), dim3(256), 0, s, desc, tile_tensor);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

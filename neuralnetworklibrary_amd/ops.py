@@ -106,6 +106,64 @@ def _pad_c4(t_nhwc):
     return torch.nn.functional.pad(t_nhwc, (0, 4 - C % 4))
 
 
+# ---- all filter transposes of a backward pass in one launch --------------------------------------------------------------
+_WT_ACTIVE = {}       # weight data_ptr -> W^T tensor [C,R,S,K]; valid ONLY between prepare_backward() and finish_backward()
+
+
+class _WtBatch:
+    "persistent W^T buffers + device descriptor tables for the conv filters of one model (nnl_conv2d_weight_transpose_multi)"
+
+    def __init__(self, weights):
+        import numpy as np
+        dev = weights[0].device
+        self.key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+        total = sum(w.numel() for w in weights)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        desc = np.zeros(len(weights), dtype=np.dtype([('w', '<u8'), ('wt', '<u8'), ('K', '<i4'), ('RS', '<i4'), ('C', '<i4'), ('first', '<i4')]))
+        tile_tensor, self.views, off, first = [], {}, 0, 0
+        for i, w in enumerate(weights):
+            K, C, R, S = w.shape
+            wt = self.flat[off:off + w.numel()].view(C, R, S, K)
+            off += w.numel()
+            n_tiles = R * S * ((K + 31) // 32) * ((C + 31) // 32)
+            desc[i] = (w.data_ptr(), wt.data_ptr(), K, R * S, C, first)
+            tile_tensor += [i] * n_tiles
+            first += n_tiles
+            self.views[w.data_ptr()] = wt
+        self.n_tiles, self.total = first, float(total)
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.tile_tensor = torch.tensor(tile_tensor, dtype=torch.int32, device=dev)
+
+    def run(self):
+        check(lib.nnl_conv2d_weight_transpose_multi(ptr(self.desc), ptr(self.tile_tensor), self.n_tiles, self.total, stream()))
+
+
+def prepare_backward(model):
+    """Call right before `loss.backward()` (Learner does): transposes the filters of every HipConv2d of `model` in ONE launch
+    (one small launch per layer otherwise) and exposes them to the convolutions' backward until finish_backward().  The
+    window is deliberately that short: a filter modified later can never meet a stale transpose."""
+    ws = [m.weight for m in model.modules()
+          if getattr(m, 'nnl_hip_conv', False) and m.weight.is_cuda and m.weight.dim() == 4 and m.weight.shape[1] % 4 == 0
+          and m.weight.shape[0] % 4 == 0 and m.weight.dtype == torch.float32
+          and m.weight.is_contiguous(memory_format=torch.channels_last)]
+    if len(ws) < 2 or sum(w.requires_grad for w in ws) * 2 < len(ws):
+        return
+    key = tuple((w.data_ptr(), tuple(w.shape)) for w in ws)
+    batch = getattr(model, '_nnl_wt_batch', None)
+    if batch is None or batch.key != key:
+        if torch.cuda.is_current_stream_capturing():
+            return                                      # (buffers are built during the eager warm-up steps)
+        batch = _WtBatch(ws)
+        object.__setattr__(model, '_nnl_wt_batch', batch)
+    batch.run()
+    _WT_ACTIVE.clear()
+    _WT_ACTIVE.update(batch.views)
+
+
+def finish_backward():
+    _WT_ACTIVE.clear()
+
+
 _TILE_COUNTERS = {}
 
 
@@ -175,8 +233,10 @@ class _Conv2d(torch.autograd.Function):
             g = _geom(g.N, g.H, g.W, g.C, dyn.shape[-1], g.R, g.S, g.stride, g.pad)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
-            check(lib.nnl_conv2d_weight_transpose(ptr(wn), ptr(wt), g.K, g.R, g.S, g.C, stream()))
+            wt = _WT_ACTIVE.get(wn.data_ptr()) if g.K == K else None
+            if wt is None or tuple(wt.shape) != (g.C, g.R, g.S, g.K):
+                wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
+                check(lib.nnl_conv2d_weight_transpose(ptr(wn), ptr(wt), g.K, g.R, g.S, g.C, stream()))
             dxn = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyn.device)
             wsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g))
             dws = torch.empty(wsb // 4, dtype=torch.float32, device=dyn.device) if wsb else None
