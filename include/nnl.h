@@ -90,8 +90,15 @@ size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g);
  * the slabs in slice order and writes the output inside the conv kernel (no separate reduce launch); each counter returns
  * to zero before the kernel ends.  NULL: the slabs are reduced by a second launch. */
 int64_t nnl_conv2d_tile_counters(void);
+/* BatchNorm statistics in the epilogue (optional; all three of bn_partials / bn_pivot / bn_rows or none): when the launch uses
+ * the 64x64 tile, the workgroup that produces the final values of a tile also writes, per tile row t = m/64 and channel c,
+ * bn_partials[(t*K + c)*2 + {0,1}] = sum over the tile's rows of (y - bn_pivot[c]) and of its square (bn_pivot: any [K] device
+ * array close to the mean, e.g. running_mean).  *bn_rows (HOST int, set before return) = number of tile rows written, or 0
+ * when this launch could not produce them (other tile shape, first-generation kernel): pass both to nnl_bn_fwd, which then
+ * skips its own statistics pass over y.  bn_partials needs ceil(N*P*Q/64) * K * 2 floats. */
 int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
-                   int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream);
+                   int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, float* bn_partials,
+                   const float* bn_pivot, int32_t* bn_rows, void* stream);
 /* wt[C,R,S,K] = transpose of w[K,R,S,C] over (K,C): the B operand of dgrad. */
 int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
 /* The same transpose for MANY filters in one launch (all convolutions of a model, once per backward pass instead of one small
@@ -130,13 +137,16 @@ int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* wor
  * training==0: normalise with running_mean / running_var.
  * y = (x-mean)*invstd*gamma + beta [+ residual] [ReLU].  save_mean/save_invstd [C] are kept for backward.
  * num_batches_tracked (device int64, may be NULL): nn.BatchNorm's step counter, incremented by the training call.
+ * ext_partials / ext_rows / ext_pivot (optional, training only): the (sum, sum of squares) partials written by the
+ * convolution that produced x (nnl_conv2d_fwd, bn_partials) with the pivot it used — the statistics pass over x is skipped.
  * relu_mask (optional, with relu != 0): ceil(rows*C/32) + 2 words; bit e of the flat [rows, C] element index is set when
  * y > 0.  Pass it to the backward instead of y: the ReLU gate then costs 1 bit instead of 32 per element of HBM traffic. */
 size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C);
 int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
                int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
-               uint32_t* relu_mask, void* workspace, size_t workspace_bytes, void* stream);
+               uint32_t* relu_mask, const float* ext_partials, int64_t ext_rows, const float* ext_pivot, void* workspace,
+               size_t workspace_bytes, void* stream);
 /* g = dy * [y > 0] (if relu; the gate comes from relu_mask when given, else from y);  dbeta = sum g;  dgamma = sum g*xhat;
  * dres = g (if dres != NULL);
  * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) (training) or gamma*invstd*g (eval). dgamma/dbeta may be NULL. */

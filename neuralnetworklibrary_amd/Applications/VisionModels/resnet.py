@@ -44,7 +44,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(ops.bn_act(self.bn1, self.conv1(x), relu=True))
+        x = self.maxpool(ops.conv_bn_act(self.conv1, self.bn1, x, relu=True))
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x).flatten(1)
         return ops.linear(x, self.fc.weight, self.fc.bias, relu=False)
@@ -58,7 +58,7 @@ class ResNetBody(nn.Sequential):
         mods = list(self.children())
         if len(mods) >= 3 and isinstance(mods[0], HipConv2d) and isinstance(mods[1], nn.BatchNorm2d) \
                 and isinstance(mods[2], nn.ReLU):
-            x = ops.bn_act(mods[1], mods[0](x), relu=True)
+            x = ops.conv_bn_act(mods[0], mods[1], x, relu=True)
             mods = mods[3:]
         for m in mods:
             x = m(x)

@@ -79,9 +79,9 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         # identity shortcut: its gradient is added inside conv1's dgrad kernel (ops.GradSlot) instead of by autograd
         slot = ops.GradSlot() if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
-        out = ops.bn_act(self.bn1, self.conv1(x, grad_slot=slot), relu=True)
+        out = ops.conv_bn_act(self.conv1, self.bn1, x, relu=True, conv_slot=slot)
         residual = x if self.downsample is None else self.downsample(x)
-        return ops.bn_act(self.bn2, self.conv2(out), residual=residual, relu=True, grad_slot=slot)
+        return ops.conv_bn_act(self.conv2, self.bn2, out, residual=residual, relu=True, bn_slot=slot)
 
 
 class Bottleneck(nn.Module):
@@ -102,17 +102,17 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         slot = ops.GradSlot() if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
-        out = ops.bn_act(self.bn1, self.conv1(x, grad_slot=slot), relu=True)
-        out = ops.bn_act(self.bn2, self.conv2(out), relu=True)
+        out = ops.conv_bn_act(self.conv1, self.bn1, x, relu=True, conv_slot=slot)
+        out = ops.conv_bn_act(self.conv2, self.bn2, out, relu=True)
         residual = x if self.downsample is None else self.downsample(x)
-        return ops.bn_act(self.bn3, self.conv3(out), residual=residual, relu=True, grad_slot=slot)
+        return ops.conv_bn_act(self.conv3, self.bn3, out, residual=residual, relu=True, bn_slot=slot)
 
 
 class _Downsample(nn.Sequential):
     "Sequential(conv1x1(stride), BN) (retinanet.py:344-348) evaluated with the fused BN epilogue"
 
     def forward(self, x):
-        return ops.bn_act(self[1], self[0](x), relu=False)
+        return ops.conv_bn_act(self[0], self[1], x, relu=False)
 
 
 class PyramidFeatures(nn.Module):
@@ -246,7 +246,7 @@ class RetinaNet(nn.Module):
         return nn.Sequential(*layers)
 
     def stem(self, x):
-        return self.maxpool(ops.bn_act(self.bn1, self.conv1(x), relu=True))
+        return self.maxpool(ops.conv_bn_act(self.conv1, self.bn1, x, relu=True))
 
     def forward(self, img_batch):
         x = self.stem(img_batch)

@@ -43,7 +43,7 @@ SIGNATURES = {
     'nnl_conv2d_fwd_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_dgrad_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_tile_counters': (i64, []),
-    'nnl_conv2d_fwd': (C.c_int, [c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), C.c_int, c_p, sz, c_p, c_p]),
+    'nnl_conv2d_fwd': (C.c_int, [c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), C.c_int, c_p, sz, c_p, c_p, c_p, C.POINTER(i32), c_p]),
     'nnl_conv2d_weight_transpose': (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_conv2d_weight_transpose_multi': (C.c_int, [c_p, c_p, i64, f64, c_p]),
     'nnl_conv2d_dgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, c_p, sz, c_p, c_p]),
@@ -76,8 +76,8 @@ SIGNATURES = {
     'nnl_optim_chunk_elems': (i64, []),
     'nnl_optim_step': (C.c_int, [c_p, c_p, c_p, i64, C.c_int, c_p, C.c_int, c_p, c_p]),
     'nnl_bn_workspace_bytes': (sz, [i64, i64]),
-    'nnl_bn_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, C.c_int, c_p, c_p, c_p, sz,
-                             c_p]),
+    'nnl_bn_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, C.c_int, c_p, c_p, c_p, i64,
+                             c_p, c_p, sz, c_p]),
     'nnl_bn_sync_stats': (C.c_int, [c_p, c_p, i64, i64, c_p, sz, c_p]),
     'nnl_bn_sync_fwd': (C.c_int, [c_p, c_p, C.c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, c_p,
                                   c_p, c_p, sz, c_p]),

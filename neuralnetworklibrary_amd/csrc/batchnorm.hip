@@ -518,7 +518,8 @@ extern "C" size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C) {
 extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                           float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
                           int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
-                          uint32_t* relu_mask, void* workspace, size_t workspace_bytes, void* stream) {
+                          uint32_t* relu_mask, const float* ext_partials, int64_t ext_rows, const float* ext_pivot,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_fwd: bad sizes rows=%ld C=%ld", (long)rows, (long)C);
   NNL_CHECK_ARG(x && y && save_mean && save_invstd, "bn_fwd: null pointer");
   NNL_CHECK_ARG(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
@@ -531,7 +532,13 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
   const int VEC = (C % 4 == 0) ? 4 : 1;
   const long CG = C / VEC;
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (training ? 12.0 : 8.0) + (residual ? 4.0 * rows * C : 0.0));
-  if (training) {
+  if (training && ext_partials != nullptr && ext_rows > 0 && ext_pivot != nullptr) {
+    // the producing convolution already reduced every 64-row tile: only the finalize (pivot = the conv's pivot)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, ext_pivot, ext_partials, (int)ext_rows,
+                       gamma, beta, save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps,
+                       momentum, (long long*)num_batches_tracked);
+    NNL_CHECK_LAUNCH();
+  } else if (training) {
     const Shape sh = make_shape(rows, CG);
     if (VEC == 4)
       hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, (long)rows, (int)C, sh.L);

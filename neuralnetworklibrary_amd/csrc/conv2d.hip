@@ -200,7 +200,10 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counte
 
 // Tile choice: estimated time = rounds of resident workgroups x per-workgroup work / per-tile MFMA efficiency.
 // Resident workgroups per CU (VGPR/LDS limited) and efficiencies are measured values (tools/bench_conv.py).
-int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0, int* counters = nullptr) {
+int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0, int* counters = nullptr,
+                  int* bn_rows = nullptr) {
+  IgemmTapsParams p = p_in;
+  if (bn_rows) *bn_rows = 0;
   const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
@@ -221,6 +224,8 @@ int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, s
       if (t < best_t) { best_t = t; best = i; }
     }
   }
+  float* const bn_part = p.bn_part;                 // statistics are produced by the 64x64 kernels only
+  p.bn_part = nullptr;
   switch (best) {
     case 0: return launch_taps<128, 128>(p, s);
     case 1: return launch_taps<128, 64>(p, s);
@@ -231,8 +236,17 @@ int dispatch_taps(const IgemmTapsParams& p, hipStream_t s, void* ws = nullptr, s
         const BalPlan pl = plan_balance(p.M, p.Nc, p.C, p.ntaps);
         if (pl.on && ws_bytes >= (pl.main_floats + pl.tail_floats) * sizeof(float)) {
           const long tiles = nnl_cdiv(p.M, pl.bm) * nnl_cdiv(p.Nc, 64);
-          return launch_balanced(p, pl, (float*)ws, tiles <= kTileCounters ? counters : nullptr, s);
+          int* const cnt = tiles <= kTileCounters ? counters : nullptr;
+          if (bn_part && dense_out && pl.bm == 64 && cnt != nullptr) {      // split tiles are finished in-kernel: stats too
+            p.bn_part = bn_part;
+            if (bn_rows) *bn_rows = (int)nnl_cdiv(p.M, 64);
+          }
+          return launch_balanced(p, pl, (float*)ws, cnt, s);
         }
+      }
+      if (bn_part && dense_out) {
+        p.bn_part = bn_part;
+        if (bn_rows) *bn_rows = (int)nnl_cdiv(p.M, 64);
       }
       // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
@@ -531,7 +545,9 @@ extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
 extern "C" int64_t nnl_conv2d_tile_counters(void) { return kTileCounters; }
 
 extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
-                              int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream) {
+                              int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, float* bn_partials,
+                              const float* bn_pivot, int32_t* bn_rows, void* stream) {
+  if (bn_rows) *bn_rows = 0;
   int st = check_geom(g, "conv2d_fwd");
   if (st) return st;
   NNL_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
@@ -558,7 +574,8 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
         q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
         q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
       }
-    return dispatch_taps(q, s, workspace, workspace_bytes, tile_counters);
+    q.bn_part = (bn_partials && bn_pivot && bn_rows) ? bn_partials : nullptr; q.bn_pivot = bn_pivot;
+    return dispatch_taps(q, s, workspace, workspace_bytes, tile_counters, bn_rows);
   }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
 }

@@ -64,6 +64,9 @@ struct IgemmTapsParams {
   int variant;                         // 1: PIPE instantiation of the 64x64 kernel (A/B: tools/bench_conv.py --ab NNL_IGEMM_VARIANT=0,1)
   float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
   float* tail_out; long tail_slab_stride;      // tail_slices > 1: slabs [tail_slices][M - tail_row0][Nc]
+  float* bn_part;                              // != null (64x64 tile, dense output): per tile row t and column c the workgroup that
+  const float* bn_pivot;                       // produces the FINAL values also writes bn_part[(t*Nc + c)*2 + {0,1}] = sum_rows (y - pivot[c]),
+                                               // sum_rows (y - pivot[c])^2 — the BatchNorm batch statistics without re-reading y
   int* tile_counters;                          // != null: the last k slice of a tile to finish (atomic ticket) sums the slabs in
                                                // slice order and writes the output itself — no separate reduce launch.  One int
                                                // per tile, ZERO at rest (the finishing workgroup resets it)
@@ -413,6 +416,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     __syncthreads();
     if (ticket != nslices - 1) return;
     if (tid == 0) __hip_atomic_store(&p.tile_counters[logical], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+    float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k4 = 0; k4 < 4; ++k4) {
       const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = n0 + (idx4 & 15) * 4;
       const int row = m0 + rl;
@@ -433,6 +437,27 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
       if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       *reinterpret_cast<f32x4*>(p.y + o) = v;
+      if (p.bn_part) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(p.bn_pivot + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; fs1[e] += d; fs2[e] += d * d; }
+      }
+    }
+    if (p.bn_part) {                              // thread t owns columns (t & 15)*4..+3 of rows t>>4, +16, +32, +48
+      __syncthreads();
+      float* red = &lds[0][0];                      // [16 row lanes][64 cols][2]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 0] = fs1[e];
+        red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 1] = fs2[e];
+      }
+      __syncthreads();
+      if (tid < 64 && n0 + tid < p.Nc) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 16; ++r) { a += red[(r * 64 + tid) * 2]; b += red[(r * 64 + tid) * 2 + 1]; }
+        p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 0] = a;
+        p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 1] = b;
+      }
     }
     return;
   }
@@ -463,6 +488,33 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
           yout[(pix - row0) * p.Nc + col] = v;
         }
       }
+    }
+  }
+  if (EPI == 0 && BM == 64 && BN == 64 && p.bn_part != nullptr && !partial) {
+    // BatchNorm statistics of this tile's 64 rows (lane l holds 16 rows of column l & 31; the two lane halves and the two
+    // row waves are combined through LDS, which is free: the k loop ended with a barrier)
+    const int col = n0 + wn * 32 + col_l;
+    const bool cok = col < p.Nc;
+    const float piv = cok ? p.bn_pivot[col] : 0.f, bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+      if (row < p.M) {
+        float v = acc[0][0][e] + bv;
+        if (p.relu) v = fmaxf(v, 0.f);
+        const float d = v - piv;
+        s1 += d; s2 += d * d;
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    float* red = &lds[0][0];                        // [2 row waves][64 cols][2]
+    if (lane < 32) { red[((wm * 64) + wn * 32 + lane) * 2] = s1; red[((wm * 64) + wn * 32 + lane) * 2 + 1] = s2; }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.Nc) {
+      p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 0] = red[tid * 2] + red[(64 + tid) * 2];
+      p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
     }
   }
 }

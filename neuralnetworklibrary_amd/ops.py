@@ -4,6 +4,9 @@ Each Function is the device-side replacement of one group of eager torch ops in 
 cited per class).  Tensors are handed over as raw device pointers + sizes on torch's CURRENT stream; there
 is no CPU fallback — a non-CUDA tensor raises NnlError.
 """
+import ctypes
+import os
+
 import torch
 
 from . import _lib
@@ -199,7 +202,7 @@ class _Conv2d(torch.autograd.Function):
     241-257,304,345) on the fp32-MFMA implicit-GEMM kernels; optional fused bias + ReLU epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, slot=None):
+    def forward(ctx, x, weight, bias, stride, pad, relu, slot=None, bn_pivot=None):
         require_cuda(x, weight, bias)
         ctx.slot = slot
         ctx.grad_dst = getattr(weight, '_nnl_grad_dst', None)     # data parallel: the flat all-reduce bucket (dist.GradSync)
@@ -212,15 +215,23 @@ class _Conv2d(torch.autograd.Function):
         b = None if bias is None else _f32c(bias)
         wsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g))         # balanced-schedule slabs (0 when the plain launch is used)
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device) if wsb else None
+        part, rows = None, _lib.i32(0)
+        if bn_pivot is not None:                                  # BatchNorm statistics from the conv epilogue (include/nnl.h)
+            part = torch.empty(((N * g.P * g.Q + 63) // 64) * K * 2, dtype=torch.float32, device=x.device)
         check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
-                                 stream()))
+                                 ptr(part), ptr(bn_pivot), ctypes.byref(rows) if part is not None else None, stream()))
+        if part is None or rows.value == 0:
+            part = torch.empty(0, dtype=torch.float32, device=x.device)
+        else:
+            part = part[:rows.value * K * 2]
+        ctx.mark_non_differentiable(part)
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
         ctx.c_in = x.shape[1]
         ctx.save_for_backward(xn, wn, y if relu else None)
-        return from_nhwc(y)
+        return from_nhwc(y), part
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dpart=None):
         xn, wn, y = ctx.saved_tensors
         g = ctx.g
         dyn = to_nhwc(dy.float())
@@ -268,13 +279,19 @@ class _Conv2d(torch.autograd.Function):
             cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device)
             check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, ptr(cws), cb, stream()))
             db = db_full[:K]
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, grad_slot=None):
     """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S].
     grad_slot: see GradSlot (the shortcut gradient of a residual block, added to dx inside the dgrad kernel)."""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu), grad_slot)
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu), grad_slot, None)[0]
+
+
+def conv2d_with_bn_stats(x, weight, bias, stride, pad, bn_pivot, grad_slot=None):
+    """conv2d whose epilogue also reduces the BatchNorm batch statistics of its output against `bn_pivot` [K].  Returns (y, partials);
+    partials is empty when this launch could not produce them (the BatchNorm then runs its own statistics pass)."""
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), False, grad_slot, bn_pivot)
 
 
 def linear(x, weight, bias=None, relu=False):
@@ -283,7 +300,7 @@ def linear(x, weight, bias=None, relu=False):
     are flattened into rows."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, bool(relu))
+    y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, bool(relu), None, None)[0]
     return y.reshape(*lead, weight.shape[0])
 
 
@@ -309,7 +326,7 @@ def _relu_mask(rows, C, device):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt, slot=None):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt, slot=None, ext=None):
         require_cuda(x, residual, gamma, beta)
         ctx.slot = slot
         xm, back = _rows_view(x)
@@ -323,7 +340,8 @@ class _BNAct(torch.autograd.Function):
         mask = _relu_mask(rows, C, xm.device) if relu else None      # 1 bit / element for the backward's ReLU gate
         check(lib.nnl_bn_fwd(ptr(xm), ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
                              ptr(running_var), rows, C, float(eps), float(momentum), int(training), int(relu), ptr(nbt),
-                             ptr(mask), ptr(ws), wsb, stream()))
+                             ptr(mask), ptr(ext[0]) if ext else None, (ext[0].numel() // (2 * C)) if ext else 0,
+                             ptr(ext[1]) if ext else None, ptr(ws), wsb, stream()))
         ctx.save_for_backward(xm, mask, gamma, mean, invstd)
         ctx.cfg = (training, relu, residual is not None, back)
         return back(y)
@@ -344,7 +362,7 @@ class _BNAct(torch.autograd.Function):
                              ptr(dgamma), ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
         if ctx.slot is not None and dres is not None:
             ctx.slot.tensor, dres = dres, None              # the block's first conv adds it to its dx (GradSlot)
-        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 8
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 9
 
 
 def _sync_group_size(group):
@@ -426,7 +444,7 @@ class DistComm:
         return out
 
 
-def bn_act(bn, x, residual=None, relu=True, grad_slot=None):
+def bn_act(bn, x, residual=None, relu=True, grad_slot=None, ext_stats=None):
     """BatchNorm (train: batch statistics + running-stat update; eval: running stats) -> (+ residual) -> ReLU in the HIP
     kernels of batchnorm.hip: the bn -> `out += residual` -> relu tail of BasicBlock / Bottleneck (reference
     retinanet.py:47-48,53-57,81-95), the stem (:372-373) and the BatchNorm1d layers (General/Layers.py:40).
@@ -447,7 +465,8 @@ def bn_act(bn, x, residual=None, relu=True, grad_slot=None):
     if sync is not None and training:
         return _SyncBNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, momentum, bn.eps, relu, nbt, sync[0], sync[1],
                                 grad_slot)
-    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt, grad_slot)
+    ext = ext_stats if (ext_stats is not None and training and ext_stats[0].numel() > 0) else None
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt, grad_slot, ext)
 
 
 class _ConcatPool(torch.autograd.Function):
@@ -470,6 +489,19 @@ class _ConcatPool(torch.autograd.Function):
         dx = torch.empty(N, H, W, C, dtype=torch.float32, device=dout.device)
         check(lib.nnl_concat_pool_bwd(ptr(_f32c(dout.reshape(N, 2 * C))), ptr(am), ptr(dx), N, H * W, C, stream()))
         return from_nhwc(dx)
+
+
+def conv_bn_act(conv, bn, x, residual=None, relu=True, conv_slot=None, bn_slot=None):
+    """bn_act(bn, conv(x), residual, relu) for a HipConv2d followed by BatchNorm — the conv -> bn -> (+shortcut) -> relu unit of the
+    ResNet blocks (retinanet.py:43-59,77-97,304-306).  In training mode the convolution's epilogue reduces the batch statistics
+    (pivot = bn.running_mean, read before the same step updates it), so the BatchNorm does not re-read the activation for them."""
+    fuse = (bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
+            and getattr(bn, 'nnl_sync', None) is None and x.is_cuda and conv.bias is None and not conv.fuse_relu
+            and torch.is_grad_enabled() and os.environ.get('NNL_BN_EPI_STATS', '1') != '0')
+    if not fuse:
+        return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot)
+    y, part = conv2d_with_bn_stats(x, conv.weight, None, conv.stride[0], conv.padding[0], bn.running_mean, conv_slot)
+    return bn_act(bn, y, residual=residual, relu=relu, grad_slot=bn_slot, ext_stats=(part, bn.running_mean))
 
 
 def concat_pool2d(x):

@@ -56,7 +56,7 @@ def ab(args):
         wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ws = torch.empty(max(wsb // 4, 1) * 4, device=dev)
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
-        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), stream())),
+        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), None, None, None, stream())),
                'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, ptr(ops._tile_counters(x.device)), stream())),
                'wgrad': lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), ws.numel() * 4, stream()))}
         for pname, fn in fns.items():
@@ -100,7 +100,7 @@ def main():
         wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
         ws = torch.empty(max(wsb // 4, 1), device=dev)
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
-        t_f = timeit(lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), stream())))
+        t_f = timeit(lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), None, None, None, stream())))
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
         t_d = timeit(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, ptr(ops._tile_counters(x.device)), stream())))
         t_w = timeit(lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), wsb, stream())))

@@ -28,7 +28,7 @@ wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ws = torch.empty(max(wsb // 
 check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
 for _ in range(a.iters):
     if a.which == 'fwd':
-        check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), stream()))
+        check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), None, None, None, stream()))
     elif a.which == 'dgrad':
         check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, ptr(ops._tile_counters(x.device)), stream()))
     else:
