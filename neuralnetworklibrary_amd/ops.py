@@ -225,6 +225,7 @@ class _Conv2d(torch.autograd.Function):
         else:
             part = part[:rows.value * K * 2]
         ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)              # no zero-filled gradient tensor for `part` in backward
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
         ctx.c_in = x.shape[1]
         ctx.save_for_backward(xn, wn, y if relu else None)
@@ -232,6 +233,8 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dpart=None):
+        if dy is None:
+            return (None,) * 8
         xn, wn, y = ctx.saved_tensors
         g = ctx.g
         dyn = to_nhwc(dy.float())
