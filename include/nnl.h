@@ -139,14 +139,15 @@ int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* wor
  * num_batches_tracked (device int64, may be NULL): nn.BatchNorm's step counter, incremented by the training call.
  * ext_partials / ext_rows / ext_pivot (optional, training only): the (sum, sum of squares) partials written by the
  * convolution that produced x (nnl_conv2d_fwd, bn_partials) with the pivot it used — the statistics pass over x is skipped.
+ * pivot_out (optional, training; may alias ext_pivot): receives this step's batch mean — the natural pivot of the next step.
  * relu_mask (optional, with relu != 0): ceil(rows*C/32) + 2 words; bit e of the flat [rows, C] element index is set when
  * y > 0.  Pass it to the backward instead of y: the ReLU gate then costs 1 bit instead of 32 per element of HBM traffic. */
 size_t nnl_bn_workspace_bytes(int64_t rows, int64_t C);
 int nnl_bn_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
                int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
-               uint32_t* relu_mask, const float* ext_partials, int64_t ext_rows, const float* ext_pivot, void* workspace,
-               size_t workspace_bytes, void* stream);
+               uint32_t* relu_mask, const float* ext_partials, int64_t ext_rows, const float* ext_pivot, float* pivot_out,
+               void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy * [y > 0] (if relu; the gate comes from relu_mask when given, else from y);  dbeta = sum g;  dgamma = sum g*xhat;
  * dres = g (if dres != NULL);
  * dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) (training) or gamma*invstd*g (eval). dgamma/dbeta may be NULL. */

@@ -77,7 +77,7 @@ SIGNATURES = {
     'nnl_optim_step': (C.c_int, [c_p, c_p, c_p, i64, C.c_int, c_p, C.c_int, c_p, c_p]),
     'nnl_bn_workspace_bytes': (sz, [i64, i64]),
     'nnl_bn_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, C.c_int, c_p, c_p, c_p, i64,
-                             c_p, c_p, sz, c_p]),
+                             c_p, c_p, c_p, sz, c_p]),
     'nnl_bn_sync_stats': (C.c_int, [c_p, c_p, i64, i64, c_p, sz, c_p]),
     'nnl_bn_sync_fwd': (C.c_int, [c_p, c_p, C.c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, c_p,
                                   c_p, c_p, sz, c_p]),

@@ -153,9 +153,11 @@ __device__ __forceinline__ void finish_stats(int c, int C, float m, float var, f
                                              const float* __restrict__ beta, float* __restrict__ mean,
                                              float* __restrict__ invstd, float* __restrict__ running_mean,
                                              float* __restrict__ running_var, float* __restrict__ scale,
-                                             float* __restrict__ shift, float eps, float momentum) {
+                                             float* __restrict__ shift, float eps, float momentum,
+                                             float* __restrict__ pivot_out = nullptr) {
   const float is = 1.f / sqrtf(var + eps);
   mean[c] = m;
+  if (pivot_out) pivot_out[c] = m;                 // next step's pivot for the conv-epilogue statistics (read above, before this)
   invstd[c] = is;
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
   if (running_var) {
@@ -174,7 +176,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
                                    float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ scale, float* __restrict__ shift, long rows, int C, float eps,
-                                   float momentum, long long* __restrict__ num_batches_tracked) {
+                                   float momentum, long long* __restrict__ num_batches_tracked,
+                                   float* __restrict__ pivot_out) {
   __shared__ float red[4][kFinLanes][2];
   const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
   float s1, s2;
@@ -185,7 +188,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __r
   const float m = x[c] + s1 / n;
   float var = (s2 - s1 * (s1 / n)) / n;
   var = fmaxf(var, 0.f);
-  finish_stats(c, C, m, var, n, gamma, beta, mean, invstd, running_mean, running_var, scale, shift, eps, momentum);
+  finish_stats(c, C, m, var, n, gamma, beta, mean, invstd, running_mean, running_var, scale, shift, eps, momentum, pivot_out);
 }
 
 // ---- cross-replica BatchNorm (SyncBN) ---------------------------------------------------------------
@@ -519,7 +522,7 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
                           float* save_mean, float* save_invstd, float* running_mean, float* running_var, int64_t rows,
                           int64_t C, float eps, float momentum, int training, int relu, int64_t* num_batches_tracked,
                           uint32_t* relu_mask, const float* ext_partials, int64_t ext_rows, const float* ext_pivot,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          float* pivot_out, void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(rows > 0 && C > 0 && C < (1 << 24), "bn_fwd: bad sizes rows=%ld C=%ld", (long)rows, (long)C);
   NNL_CHECK_ARG(x && y && save_mean && save_invstd, "bn_fwd: null pointer");
   NNL_CHECK_ARG(training || (running_mean && running_var), "bn_fwd: eval mode needs running statistics");
@@ -536,7 +539,7 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
     // the producing convolution already reduced every 64-row tile: only the finalize (pivot = the conv's pivot)
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, ext_pivot, ext_partials, (int)ext_rows,
                        gamma, beta, save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps,
-                       momentum, (long long*)num_batches_tracked);
+                       momentum, (long long*)num_batches_tracked, pivot_out);
     NNL_CHECK_LAUNCH();
   } else if (training) {
     const Shape sh = make_shape(rows, CG);
@@ -547,7 +550,7 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
     NNL_CHECK_LAUNCH();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
                        save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps, momentum,
-                       (long long*)num_batches_tracked);
+                       (long long*)num_batches_tracked, pivot_out);
     NNL_CHECK_LAUNCH();
   } else {
     NNL_CHECK_HIP(hipMemcpyAsync(save_mean, running_mean, sizeof(float) * C, hipMemcpyDeviceToDevice, s));

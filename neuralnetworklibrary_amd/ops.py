@@ -329,7 +329,8 @@ def _relu_mask(rows, C, device):
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt, slot=None, ext=None):
+    def forward(ctx, x, residual, gamma, beta, running_mean, running_var, training, momentum, eps, relu, nbt, slot=None, ext=None,
+                pivot_out=None):
         require_cuda(x, residual, gamma, beta)
         ctx.slot = slot
         xm, back = _rows_view(x)
@@ -344,7 +345,7 @@ class _BNAct(torch.autograd.Function):
         check(lib.nnl_bn_fwd(ptr(xm), ptr(gamma), ptr(beta), ptr(rm), ptr(y), ptr(mean), ptr(invstd), ptr(running_mean),
                              ptr(running_var), rows, C, float(eps), float(momentum), int(training), int(relu), ptr(nbt),
                              ptr(mask), ptr(ext[0]) if ext else None, (ext[0].numel() // (2 * C)) if ext else 0,
-                             ptr(ext[1]) if ext else None, ptr(ws), wsb, stream()))
+                             ptr(ext[1]) if ext else None, ptr(pivot_out), ptr(ws), wsb, stream()))
         ctx.save_for_backward(xm, mask, gamma, mean, invstd)
         ctx.cfg = (training, relu, residual is not None, back)
         return back(y)
@@ -365,7 +366,7 @@ class _BNAct(torch.autograd.Function):
                              ptr(dgamma), ptr(dbeta), rows, C, int(training), int(relu), ptr(ws), wsb, stream()))
         if ctx.slot is not None and dres is not None:
             ctx.slot.tensor, dres = dres, None              # the block's first conv adds it to its dx (GradSlot)
-        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 9
+        return (back(dx), None if dres is None else back(dres), dgamma, dbeta) + (None,) * 10
 
 
 def _sync_group_size(group):
@@ -447,7 +448,7 @@ class DistComm:
         return out
 
 
-def bn_act(bn, x, residual=None, relu=True, grad_slot=None, ext_stats=None):
+def bn_act(bn, x, residual=None, relu=True, grad_slot=None, ext_stats=None, pivot_out=None):
     """BatchNorm (train: batch statistics + running-stat update; eval: running stats) -> (+ residual) -> ReLU in the HIP
     kernels of batchnorm.hip: the bn -> `out += residual` -> relu tail of BasicBlock / Bottleneck (reference
     retinanet.py:47-48,53-57,81-95), the stem (:372-373) and the BatchNorm1d layers (General/Layers.py:40).
@@ -469,7 +470,8 @@ def bn_act(bn, x, residual=None, relu=True, grad_slot=None, ext_stats=None):
         return _SyncBNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, momentum, bn.eps, relu, nbt, sync[0], sync[1],
                                 grad_slot)
     ext = ext_stats if (ext_stats is not None and training and ext_stats[0].numel() > 0) else None
-    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt, grad_slot, ext)
+    return _BNAct.apply(x, residual, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, relu, nbt, grad_slot, ext,
+                        pivot_out if training else None)
 
 
 class _ConcatPool(torch.autograd.Function):
@@ -497,14 +499,24 @@ class _ConcatPool(torch.autograd.Function):
 def conv_bn_act(conv, bn, x, residual=None, relu=True, conv_slot=None, bn_slot=None):
     """bn_act(bn, conv(x), residual, relu) for a HipConv2d followed by BatchNorm — the conv -> bn -> (+shortcut) -> relu unit of the
     ResNet blocks (retinanet.py:43-59,77-97,304-306).  In training mode the convolution's epilogue reduces the batch statistics
-    (pivot = bn.running_mean, read before the same step updates it), so the BatchNorm does not re-read the activation for them."""
+    as shifted sums sum(y - pivot), sum((y - pivot)^2), so the BatchNorm does not re-read the activation for them.  The pivot is
+    the batch mean of the PREVIOUS training step of this layer (kept in `bn._nnl_pivot`, written by the finalize kernel): it
+    sits within a fraction of a standard deviation of the new mean, which keeps the variance free of cancellation; the first
+    step (no pivot yet) runs the stand-alone statistics pass."""
     fuse = (bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
             and getattr(bn, 'nnl_sync', None) is None and x.is_cuda and conv.bias is None and not conv.fuse_relu
             and torch.is_grad_enabled() and os.environ.get('NNL_BN_EPI_STATS', '1') != '0')
     if not fuse:
         return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot)
-    y, part = conv2d_with_bn_stats(x, conv.weight, None, conv.stride[0], conv.padding[0], bn.running_mean, conv_slot)
-    return bn_act(bn, y, residual=residual, relu=relu, grad_slot=bn_slot, ext_stats=(part, bn.running_mean))
+    pivot = getattr(bn, '_nnl_pivot', None)
+    if pivot is None or pivot.device != x.device or pivot.numel() != bn.num_features:
+        if torch.cuda.is_current_stream_capturing():
+            return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot)
+        pivot = torch.empty(bn.num_features, dtype=torch.float32, device=x.device)
+        object.__setattr__(bn, '_nnl_pivot', pivot)                  # plain attribute: not a buffer, not in the state_dict
+        return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot, pivot_out=pivot)
+    y, part = conv2d_with_bn_stats(x, conv.weight, None, conv.stride[0], conv.padding[0], pivot, conv_slot)
+    return bn_act(bn, y, residual=residual, relu=relu, grad_slot=bn_slot, ext_stats=(part, pivot), pivot_out=pivot)
 
 
 def concat_pool2d(x):
