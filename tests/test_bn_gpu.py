@@ -64,3 +64,47 @@ def test_bn_act(case):
     assert_close(bn_g.running_mean, bn_c.running_mean, 1e-5, 1e-5, 'running_mean')
     assert_close(bn_g.running_var, bn_c.running_var, 1e-4, 1e-6, 'running_var')
     assert int(bn_g.num_batches_tracked) == int(bn_c.num_batches_tracked)
+
+
+@pytest.mark.parametrize('offset', [0.0, 40.0], ids=['centred', 'mean>>std'])
+def test_conv_bn_act_epilogue_statistics(offset):
+    """ops.conv_bn_act: from a layer's second training step on, the batch statistics come from the convolution's epilogue
+    (shifted sums around the previous step's batch mean).  Output, running statistics and all gradients must match
+    conv2d -> BatchNorm2d -> +residual in fp64, also when the running mean is useless as a pivot (never updated towards
+    a batch mean that sits 20+ sigma away) and when the data mean moves between steps."""
+    from neuralnetworklibrary_amd import ops
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
+    g = torch.Generator().manual_seed(11)
+    N, Ci, Co, S = 8, 64, 128, 28                       # 6272 output rows: balanced / plain 64x64 tiles with tail rows
+    conv = HipConv2d(Ci, Co, 3, stride=1, padding=1, bias=False).to(DEV)
+    bn = nn.BatchNorm2d(Co).to(DEV)
+    w64 = conv.weight.detach().double().cpu()
+    ref_bn = nn.BatchNorm2d(Co).double()
+    conv.train(); bn.train(); ref_bn.train()
+    for step in range(3):
+        x = torch.randn(N, Ci, S, S, generator=g) + offset * (1 + 0.05 * step)
+        res = torch.randn(N, Co, S, S, generator=g)
+        dy = torch.randn(N, Co, S, S, generator=g)
+        xg, rg = x.to(DEV).requires_grad_(True), res.to(DEV).requires_grad_(True)
+        for p in list(conv.parameters()) + list(bn.parameters()):
+            p.grad = None
+        yg = ops.conv_bn_act(conv, bn, xg, residual=rg, relu=False)   # no ReLU: a gate flipped by rounding would move dx by O(1)
+        ops.prepare_backward(torch.nn.Sequential(conv, bn))
+        yg.backward(dy.to(DEV))
+        ops.finish_backward()
+        assert (getattr(bn, '_nnl_pivot', None) is not None)
+
+        xc, rc = x.double().requires_grad_(True), res.double().requires_grad_(True)
+        wc = w64.clone().requires_grad_(True)
+        for p in ref_bn.parameters():
+            p.grad = None
+        yc = ref_bn(torch.nn.functional.conv2d(xc, wc, None, 1, 1)) + rc
+        yc.backward(dy.double())
+        tag = 'step %d ' % step
+        assert_close(yg, yc.float(), 2e-4, 2e-4, tag + 'y')
+        assert_close(bn.running_mean, ref_bn.running_mean.float(), 1e-4, 1e-5, tag + 'running_mean')
+        assert_close(bn.running_var, ref_bn.running_var.float(), 1e-3, 1e-5, tag + 'running_var')
+        assert_close(bn._nnl_pivot, torch.nn.functional.conv2d(xc, wc, None, 1, 1).mean((0, 2, 3)).float(), 1e-4, 1e-4, tag + 'pivot')
+        for name, a, b in (('dx', xg.grad, xc.grad), ('dres', rg.grad, rc.grad), ('dw', conv.weight.grad, wc.grad),
+                           ('dgamma', bn.weight.grad, ref_bn.weight.grad), ('dbeta', bn.bias.grad, ref_bn.bias.grad)):
+            assert_close(a, b.float(), 2e-3, 2e-3 * b.abs().max().item(), tag + name)
