@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported first: libnnl_hip.so binds to the libamdhip64.so.7 torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnnl_hip.so')
+LIB_PATH = os.environ.get('NNL_LIB_PATH') or os.path.join(_HERE, 'libnnl_hip.so')   # NNL_LIB_PATH: A/B another BUILD of the same ABI
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

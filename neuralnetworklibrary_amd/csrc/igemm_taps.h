@@ -175,16 +175,22 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   }
 
   f32x4 ra[PA], rb[PB];
-  auto load_tile = [&](int t, int c0) {
-    const int a_soff = (p.tap_aoff[t] + c0) * 4;         // scalar; may be negative -> folded into the per-lane offset
-    const unsigned b_soff = (unsigned)(p.tap_woff[t] + c0) * 4u;
+  // Per-TAP state, refreshed only when the k loop crosses into another tap (every C/BK iterations): the per-row byte offsets of
+  // the tap's pixel (or an out-of-range offset for a padded / ragged row, which the buffer load turns into zeros) and the two
+  // scalar table entries.  The steady-state iteration is then just buffer loads at (per-lane offset, scalar channel offset).
+  unsigned a_voff[PA];
+  unsigned b_tap = 0;
+  auto set_tap = [&](int t) {
+    const int a_tap = p.tap_aoff[t] * 4;                 // may be negative; the sum with a valid row's base is not
+    b_tap = (unsigned)p.tap_woff[t] * 4u;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const bool ok = (a_mask[i] >> t) & 1ull;
-      ra[i] = buf_load4(ra_src, ok ? (unsigned)(a_off[i] + a_soff) : 0xFFFFFFFFu, 0);
-    }
+    for (int i = 0; i < PA; ++i) a_voff[i] = ((a_mask[i] >> t) & 1ull) ? (unsigned)(a_off[i] + a_tap) : 0xFFFFFFFFu;
+  };
+  auto load_tile = [&](int c0) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, b_off[i], b_soff);
+    for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, a_voff[i], (unsigned)c0 * 4u);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, b_off[i], b_tap + (unsigned)c0 * 4u);
   };
   auto store_tile = [&](int buf) {
     float* As = lds[buf];
@@ -278,19 +284,19 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   }
   int t_nx = kt0 / csteps, c_nx = (kt0 - t_nx * csteps) * BK;       // (tap, c0) of the NEXT tile to fetch
   if (nk > 0) {
-    load_tile(t_nx, c_nx);
+    set_tap(t_nx);
+    load_tile(c_nx);
     store_tile(0);
   }
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // advance to tile kt+1, clamped to the last tile (the final iteration re-fetches it; harmless)
-    int c_try = c_nx + BK, t_try = t_nx;
-    if (c_try >= p.C) { c_try = 0; t_try = t_nx + 1; }
-    const bool more = kt + 1 < nk;
-    t_nx = more ? t_try : t_nx;
-    c_nx = more ? c_try : c_nx;
-    load_tile(t_nx, c_nx);                     // buffer loads of tile kt+1 go out FIRST ...
+    // advance to tile kt+1 (the final iteration re-fetches the last tile instead: harmless, keeps the body uniform)
+    if (kt + 1 < nk) {
+      c_nx += BK;
+      if (c_nx >= p.C) { c_nx = 0; ++t_nx; set_tap(t_nx); }      // wave-uniform branch, once per tap
+    }
+    load_tile(c_nx);                           // buffer loads of tile kt+1 go out FIRST ...
     __builtin_amdgcn_sched_barrier(0);         // ... (keep the compiler from sinking them behind the MFMAs to save VGPRs)
     compute(cur);                              // 32 MFMAs per wave cover their latency
     __builtin_amdgcn_sched_barrier(0);
