@@ -417,7 +417,6 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   q.H = H; q.W = W; q.C = C; q.P = P; q.Q = Q; q.R = R; q.S = S; q.stride = stride; q.pad = pad;
   q.Mc = Mc; q.Nc = Nc; q.Kp = (int)Kp;
   q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
-  q.rcp_PQ = 1.0f / (float)(P * Q); q.rcp_Q = 1.0f / (float)Q;
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
   const char* e_bk = getenv("NNL_WGRAD_BK32");                       // tuning hook
   const int bk32 = e_bk ? atoi(e_bk) : 0;

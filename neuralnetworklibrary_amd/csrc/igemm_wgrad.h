@@ -3,8 +3,7 @@
 // Both operands are k-major (rows = pixels, channels contiguous): LDS tiles [BK][BM] / [BK][BN], ds_read_b32 fragments.
 // Against the first-generation kernel (igemm_kernels.h: igemm_kmajor_kernel): operands come through BUFFER loads with
 // per-lane 32-bit offsets (invalid pixels / ragged edges / rows past the split get an out-of-range offset and read 0:
-// no branches), the per-row pixel decode uses a float-reciprocal division with a +-1 fix-up instead of two integer
-// divisions, the loads of tile t+1 are pinned ahead of the MFMAs of tile t, and __launch_bounds__ keeps 4-5 waves/SIMD.
+// no branches), the per-row pixel decode is incremental (BK pixels per k tile: adds and selects, no division), the loads of tile t+1 are pinned ahead of the MFMAs of tile t, and __launch_bounds__ keeps 4-5 waves/SIMD.
 // grid = grid_m * grid_n * splits; split s reduces pixels [s*k_per_split, (s+1)*k_per_split) into its own slab.
 #pragma once
 #include "igemm_taps.h"
@@ -18,7 +17,6 @@ struct IgemmWgradParams {
   int R, S, stride, pad;
   int Mc, Nc, Kp;
   int splits, k_per_split, grid_m, grid_n;
-  float rcp_PQ, rcp_Q;
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false>
@@ -59,26 +57,55 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   const int dh = br - p.pad, dw = bs - p.pad;
 
   f32x4 ra[PA], rb[PB];
-  auto load_tile = [&](int k0) {
+  // Per-row gather state, advanced INCREMENTALLY by BK pixels per k tile (no division, multiplication or branch in the loop):
+  // a pixel index k = (n, pp, qq) moves by BK = dn*P*Q + dp*Q + dq, with at most one carry out of qq and one out of pp; the
+  // byte offset of its input pixel moves by a constant plus one constant per carry.  Row validity is two unsigned range
+  // tests on (pp, qq) against per-thread bounds (the thread's tap (dh, dw) is fixed) and k < k_end.
+  const int adv_n = BK / PQ, adv_r = BK - adv_n * PQ, adv_p = adv_r / p.Q, adv_q = adv_r - adv_p * p.Q;
+  const int step_px = p.stride * p.C * 4;                                    // bytes per unit of qq
+  const int step_row = p.stride * p.W * p.C * 4;                             // bytes per unit of pp
+  const int off_adv = adv_n * p.H * p.W * p.C * 4 + adv_p * step_row + adv_q * step_px;
+  const int off_qwrap = step_row - p.Q * step_px;                            // qq -= Q, pp += 1
+  const int off_pwrap = p.H * p.W * p.C * 4 - p.P * step_row;                // pp -= P, n += 1
+  // pp valid  <=>  0 <= pp*stride + dh < H  <=>  pp in [pp_lo, pp_hi)
+  const int pp_lo = dh < 0 ? (-dh + p.stride - 1) / p.stride : 0, qq_lo = dw < 0 ? (-dw + p.stride - 1) / p.stride : 0;
+  const int pp_hi = min(p.P, (p.H - dh + p.stride - 1) / p.stride), qq_hi = min(p.Q, (p.W - dw + p.stride - 1) / p.stride);
+  const unsigned pp_span = pp_hi > pp_lo ? (unsigned)(pp_hi - pp_lo) : 0u, qq_span = qq_hi > qq_lo ? (unsigned)(qq_hi - qq_lo) : 0u;
+  int a_k[PA]; unsigned a_off[PA];
+  int b_k[PB], b_pp[PB], b_qq[PB], b_off[PB];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int k = k0 + ra_row + i * RA;
-      const bool ok = a_cok && k < k_end;
-      ra[i] = buf_load4(ra_src, ok ? (unsigned)(k * p.Mc + a_col) * 4u : 0xFFFFFFFFu, 0);
-    }
+  for (int i = 0; i < PA; ++i) {
+    a_k[i] = k_begin + ra_row + i * RA;
+    a_off[i] = (unsigned)(a_k[i] * p.Mc + a_col) * 4u;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int k = k_begin + rb_row + i * RB;
+    const int n = k / PQ, rem = k - n * PQ;
+    b_k[i] = k; b_pp[i] = rem / p.Q; b_qq[i] = rem - b_pp[i] * p.Q;
+    b_off[i] = (((n * p.H + b_pp[i] * p.stride + dh) * p.W + b_qq[i] * p.stride + dw) * p.C + bc) * 4;
+  }
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) { a_k[i] += BK; a_off[i] += (unsigned)(BK * p.Mc) * 4u; }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      const int k = k0 + rb_row + i * RB;
-      // (n, pp, qq) = decode(k): float-reciprocal quotient, exact after a +-1 correction (k < 2^23)
-      int n = (int)((float)k * p.rcp_PQ);
-      int rem = k - n * PQ;
-      if (rem < 0) { rem += PQ; n -= 1; } else if (rem >= PQ) { rem -= PQ; n += 1; }
-      int pp = (int)((float)rem * p.rcp_Q);
-      int qq = rem - pp * p.Q;
-      if (qq < 0) { qq += p.Q; pp -= 1; } else if (qq >= p.Q) { qq -= p.Q; pp += 1; }
-      const int h = pp * p.stride + dh, w = qq * p.stride + dw;
-      const bool ok = b_cok && k < k_end && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-      rb[i] = buf_load4(rb_src, ok ? (unsigned)(((n * p.H + h) * p.W + w) * p.C + bc) * 4u : 0xFFFFFFFFu, 0);
+      b_k[i] += BK;
+      int qq = b_qq[i] + adv_q, pp = b_pp[i] + adv_p, off = b_off[i] + off_adv;
+      const bool qw = qq >= p.Q;
+      qq -= qw ? p.Q : 0; pp += qw ? 1 : 0; off += qw ? off_qwrap : 0;
+      const bool pw = pp >= p.P;
+      pp -= pw ? p.P : 0; off += pw ? off_pwrap : 0;
+      b_qq[i] = qq; b_pp[i] = pp; b_off[i] = off;
+    }
+  };
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, (a_cok && a_k[i] < k_end) ? a_off[i] : 0xFFFFFFFFu, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      const bool ok = b_cok && b_k[i] < k_end && (unsigned)(b_pp[i] - pp_lo) < pp_span && (unsigned)(b_qq[i] - qq_lo) < qq_span;
+      rb[i] = buf_load4(rb_src, ok ? (unsigned)b_off[i] : 0xFFFFFFFFu, 0);
     }
   };
   auto store_tile = [&](int buf) {
@@ -145,13 +172,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
 
   const int nk = (k_end - k_begin + BK - 1) / BK;
   if (nk > 0) {
-    load_tile(k_begin);
+    load_tile();
     store_tile(0);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      const int k_next = k_begin + min(kt + 1, nk - 1) * BK;      // the last iteration re-fetches the last tile (no branch)
-      load_tile(k_next);
+      if (kt + 1 < nk) advance();                // the last iteration re-fetches the last tile (uniform; keeps one loop body)
+      load_tile();
       __builtin_amdgcn_sched_barrier(0);
       compute(cur);
       __builtin_amdgcn_sched_barrier(0);
