@@ -34,8 +34,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int tiles = p.grid_m * p.grid_n;
-  const int split = blockIdx.x / tiles;
-  const int t_id = blockIdx.x - split * tiles;
+  // XCD-aware order: the hardware deals workgroups round-robin over the 8 XCDs; the remap gives each XCD a CONTIGUOUS range of
+  // (split, tile) pairs, so the tiles of one split — which all stream the same pixel range of dy and x — share one L2
+  const int lb = nnl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int split = lb / tiles;
+  const int t_id = lb - split * tiles;
   const int tile_n = t_id / p.grid_m, tile_m = t_id - tile_n * p.grid_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int k_begin = split * p.k_per_split;
