@@ -54,15 +54,19 @@ int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   return launch_rowk<64, 64, 2, 2, MODE>(p, s);
 }
 
+static int os_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }   // A/B hooks, re-read per call
+
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
   { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
+  p.cls_tiles = p.grid_m * p.grid_n;
+  const unsigned gx = (unsigned)(p.grid_m * p.grid_n * (p.ncls > 1 ? p.ncls : 1));
   if (BM == 64 && BN == 64 && p.variant == 1)
-    hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2, true>), dim3(p.grid_m * p.grid_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2, true>), dim3(gx, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(p.grid_m * p.grid_n, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2>), dim3(gx, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -214,7 +218,7 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
     double best_t = 1e300;
     for (int i = 0; i < 4; ++i) {
       const Cand& c = cands[i];
-      const long blocks = nnl_cdiv(p.M, c.bm) * nnl_cdiv(p.Nc, c.bn);
+      const long blocks = nnl_cdiv(p.M, c.bm) * nnl_cdiv(p.Nc, c.bn) * (p.ncls > 1 ? p.ncls : 1);
       const long slots = 256L * c.occ;
       const long rounds = nnl_cdiv(blocks, slots);
       // inside one round the CU is shared by min(occ, blocks/256) workgroups: time ~ (workgroups on the busiest CU) x tile work
@@ -251,7 +255,7 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
       // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
       const char* e_bk = getenv("NNL_IGEMM_BK32");
-      const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64);
+      const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64) * (p.ncls > 1 ? p.ncls : 1);
       const int bk32 = e_bk ? atoi(e_bk) : (blocks64 < 1200);
       if (bk32 && p.C % 32 == 0) return launch_taps<64, 64, 32>(p, s);
       return launch_taps<64, 64>(p, s);
@@ -629,33 +633,62 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
     const int st2 = g->stride;
     // one launch per output-parity class (a single class when stride == 1): dx pixel (st*hh + ph, st*ww + pw) receives
     // exactly the taps r with (ph + pad - r) % st == 0, from dy pixel hh + (ph + pad - r)/st
+    struct Cls { int ph, pw, P, Q, nt; signed char dh[IGEMM_MAX_TAPS], dw[IGEMM_MAX_TAPS]; int aoff[IGEMM_MAX_TAPS], woff[IGEMM_MAX_TAPS]; };
+    Cls cls[4];
+    int ncls = 0;
     bool need_zero = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1 && need_zero) NNL_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * g->N * g->H * g->W * g->C, s));
-      for (int ph = 0; ph < st2; ++ph)
-        for (int pw = 0; pw < st2; ++pw) {
-          IgemmTapsParams c = q;
-          c.P = (g->H - ph + st2 - 1) / st2; c.Q = (g->W - pw + st2 - 1) / st2;
-          c.out_stride = st2; c.oh0 = ph; c.ow0 = pw;
-          c.M = g->N * c.P * c.Q;
-          int nt = 0;
-          for (int r = 0; r < g->R; ++r) {
-            if ((ph + g->pad - r) % st2 != 0) continue;
-            for (int ss = 0; ss < g->S; ++ss) {
-              if ((pw + g->pad - ss) % st2 != 0) continue;
-              const int dh = (ph + g->pad - r) / st2, dw = (pw + g->pad - ss) / st2;
-              c.tap_dh[nt] = (signed char)dh; c.tap_dw[nt] = (signed char)dw;
-              c.tap_aoff[nt] = (dh * g->Q + dw) * g->K; c.tap_woff[nt] = (r * g->S + ss) * g->K;
-              ++nt;
-            }
+    for (int ph = 0; ph < st2; ++ph)
+      for (int pw = 0; pw < st2; ++pw) {
+        Cls c{};
+        c.ph = ph; c.pw = pw;
+        c.P = (g->H - ph + st2 - 1) / st2; c.Q = (g->W - pw + st2 - 1) / st2;
+        for (int r = 0; r < g->R; ++r) {
+          if ((ph + g->pad - r) % st2 != 0) continue;
+          for (int ss = 0; ss < g->S; ++ss) {
+            if ((pw + g->pad - ss) % st2 != 0) continue;
+            const int dh = (ph + g->pad - r) / st2, dw = (pw + g->pad - ss) / st2;
+            c.dh[c.nt] = (signed char)dh; c.dw[c.nt] = (signed char)dw;
+            c.aoff[c.nt] = (dh * g->Q + dw) * g->K; c.woff[c.nt] = (r * g->S + ss) * g->K;
+            ++c.nt;
           }
-          c.ntaps = nt;
-          if (c.M <= 0) continue;
-          if (nt == 0) { need_zero = true; continue; }
-          if (pass == 0) continue;                      // first pass only finds out whether dx needs a zero fill
-          int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes, tile_counters);
-          if (st) return st;
         }
+        if (c.P <= 0 || c.Q <= 0) continue;
+        if (c.nt == 0) { need_zero = true; continue; }      // no filter tap reaches this parity class: its dx pixels are zero
+        cls[ncls++] = c;
+      }
+    if (need_zero) NNL_CHECK_HIP(hipMemsetAsync(dx, 0, sizeof(float) * g->N * g->H * g->W * g->C, s));
+    auto fill = [&](IgemmTapsParams& c, const Cls& k, int at) {
+      for (int t = 0; t < k.nt; ++t) {
+        c.tap_dh[at + t] = k.dh[t]; c.tap_dw[at + t] = k.dw[t]; c.tap_aoff[at + t] = k.aoff[t]; c.tap_woff[at + t] = k.woff[t];
+      }
+    };
+    // all classes in ONE launch when they have the same row count (even H, W): longest classes first
+    bool merged = ncls > 1 && os_env_int("NNL_DGRAD_MERGE", 1) != 0;
+    for (int i = 1; i < ncls && merged; ++i) merged = cls[i].P == cls[0].P && cls[i].Q == cls[0].Q;
+    if (merged) {
+      for (int i = 1; i < ncls; ++i)                        // insertion sort by decreasing tap count (<= 4 entries)
+        for (int j = i; j > 0 && cls[j].nt > cls[j - 1].nt; --j) { const Cls t = cls[j]; cls[j] = cls[j - 1]; cls[j - 1] = t; }
+      IgemmTapsParams c = q;
+      c.P = cls[0].P; c.Q = cls[0].Q; c.M = g->N * c.P * c.Q;
+      c.out_stride = st2; c.oh0 = cls[0].ph; c.ow0 = cls[0].pw;
+      c.ncls = ncls;
+      int at = 0;
+      for (int i = 0; i < ncls; ++i) {
+        c.cls_tap0[i] = at; c.cls_ntaps[i] = cls[i].nt; c.cls_oh0[i] = cls[i].ph; c.cls_ow0[i] = cls[i].pw;
+        fill(c, cls[i], at);
+        at += cls[i].nt;
+      }
+      c.ntaps = cls[0].nt;
+      return dispatch_taps(c, s, nullptr, 0, tile_counters);
+    }
+    for (int i = 0; i < ncls; ++i) {
+      IgemmTapsParams c = q;
+      c.P = cls[i].P; c.Q = cls[i].Q; c.M = g->N * c.P * c.Q;
+      c.out_stride = st2; c.oh0 = cls[i].ph; c.ow0 = cls[i].pw;
+      fill(c, cls[i], 0);
+      c.ntaps = cls[i].nt;
+      int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes, tile_counters);
+      if (st) return st;
     }
     return NNL_OK;
   }

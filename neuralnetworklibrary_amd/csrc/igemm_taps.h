@@ -70,6 +70,12 @@ struct IgemmTapsParams {
   int* tile_counters;                          // != null: the last k slice of a tile to finish (atomic ticket) sums the slabs in
                                                // slice order and writes the output itself — no separate reduce launch.  One int
                                                // per tile, ZERO at rest (the finishing workgroup resets it)
+  // Output-parity CLASSES in one launch (ncls > 1; stride-2 dgrad with even OH, OW): workgroup tiles [c*cls_tiles, (c+1)*cls_tiles)
+  // belong to class c, which owns taps [cls_tap0[c], cls_tap0[c] + cls_ntaps[c]) of the tables below and writes the output
+  // pixels (out_stride*pp + cls_oh0[c], out_stride*qq + cls_ow0[c]); the host orders the classes by decreasing tap count, so
+  // the long tiles start first and the short ones fill the tail of the launch (M, P, Q are per class and equal for all).
+  int ncls, cls_tiles;
+  int cls_tap0[4], cls_ntaps[4], cls_oh0[4], cls_ow0[4];
   int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
   int tap_woff[IGEMM_MAX_TAPS];        // offset of the tap's C weights inside a B row, elements
   signed char tap_dh[IGEMM_MAX_TAPS], tap_dw[IGEMM_MAX_TAPS];
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
-  int logical, kslice = 0, nslices = 1, row0 = 0;
+  int logical, kslice = 0, nslices = 1, row0 = 0, cls = 0;
   bool in_tail = false;
   float* yout = p.y;
   if (p.bal) {
@@ -126,9 +132,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       nslices = p.tail_slices;
       if (nslices > 1) { yout = p.tail_out + (long)kslice * p.tail_slab_stride; row0 = p.tail_row0; in_tail = true; }
     }
+  } else if (p.ncls > 1) {
+    // classes run one after the other in launch order (longest first); the XCD remap is applied INSIDE a class, so every XCD
+    // gets its share of each class (a remap of the whole grid would hand the long classes to XCDs 0-1 and the short to 6-7)
+    cls = (int)blockIdx.x / p.cls_tiles;
+    logical = nnl_xcd_remap((int)blockIdx.x - cls * p.cls_tiles, p.cls_tiles);
   } else {
     logical = nnl_xcd_remap(blockIdx.x, gridDim.x);
     if (p.ksplit > 1) { kslice = (int)blockIdx.y; nslices = p.ksplit; yout = p.y + (long)blockIdx.y * p.slab_stride; }
+  }
+  int tap0 = 0, ntaps = p.ntaps, oh0 = p.oh0, ow0 = p.ow0;
+  if (p.ncls > 1) {
+    tap0 = p.cls_tap0[cls]; ntaps = p.cls_ntaps[cls]; oh0 = p.cls_oh0[cls]; ow0 = p.cls_ow0[cls];
   }
   const bool partial = nslices > 1;            // partial sums: no bias / add / ReLU (the reduce kernel applies them)
   const int tile_m = logical / p.grid_n, tile_n = logical - tile_m * p.grid_n;
@@ -155,8 +170,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     a_off[i] = (((n * p.H + h0) * p.W + w0) * p.C + kc * 4) * 4;
     unsigned long long mask = 0;
     if (valid)
-      for (int t = 0; t < p.ntaps; ++t) {
-        const int h = h0 + p.tap_dh[t], w = w0 + p.tap_dw[t];
+      for (int t = 0; t < ntaps; ++t) {
+        const int h = h0 + p.tap_dh[tap0 + t], w = w0 + p.tap_dw[tap0 + t];
         if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) mask |= 1ull << t;
       }
     a_mask[i] = mask;
@@ -181,8 +196,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   unsigned a_voff[PA];
   unsigned b_tap = 0;
   auto set_tap = [&](int t) {
-    const int a_tap = p.tap_aoff[t] * 4;                 // may be negative; the sum with a valid row's base is not
-    b_tap = (unsigned)p.tap_woff[t] * 4u;
+    const int a_tap = p.tap_aoff[tap0 + t] * 4;          // may be negative; the sum with a valid row's base is not
+    b_tap = (unsigned)p.tap_woff[tap0 + t] * 4u;
 #pragma unroll
     for (int i = 0; i < PA; ++i) a_voff[i] = ((a_mask[i] >> t) & 1ull) ? (unsigned)(a_off[i] + a_tap) : 0xFFFFFFFFu;
   };
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 
   // ---- k loop: scalar state (tap, channel offset); the body has no branches ----
   const int csteps = p.C / BK;
-  const int nk_all = p.ntaps * csteps;
+  const int nk_all = ntaps * csteps;
   int kt0 = 0, nk = nk_all;
   if (partial) {                               // split-K: this workgroup reduces k tiles [kt0, kt0 + nk)
     const int per = (nk_all + nslices - 1) / nslices;
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     return;
   }
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
-  const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (p.oh0 == 0) && (p.ow0 == 0);
+  const bool dense_out = (p.out_stride == 1) && (p.OH == p.P) && (p.OW == p.Q) && (oh0 == 0) && (ow0 == 0);
   if (EPI == 0 && BM == 64 && BN == 64 && p.bal && partial && p.tile_counters != nullptr) {
     // ---- in-kernel fix-up of a split tile (same hand-over as the fused LSTM step: sc1 stores, drain, ticket, sc1 loads) ----
     __shared__ int ticket;
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
             const int rem = row - n * PQ;
             const int pp = rem / p.Q;
             const int qq = rem - pp * p.Q;
-            pix = ((long)n * p.OH + pp * p.out_stride + p.oh0) * p.OW + qq * p.out_stride + p.ow0;
+            pix = ((long)n * p.OH + pp * p.out_stride + oh0) * p.OW + qq * p.out_stride + ow0;
           }
           float v = acc[i][j][e] + bv;
           if (!partial) {

@@ -26,6 +26,9 @@ CASES = [
     (2, 8, 13, 11, 12, 3, 1, 1, True, False),       # ragged: odd sizes, tiny channels
     (1, 4, 5, 5, 4, 3, 2, 1, False, False),         # tiny
     (5, 16, 9, 9, 20, 3, 2, 1, True, True),
+    (2, 32, 15, 15, 32, 3, 2, 1, False, False),     # strided dgrad, odd size: one launch per output-parity class
+    (2, 16, 24, 20, 16, 7, 2, 3, False, False),     # strided dgrad, 49 taps in four parity classes of ONE launch
+    (3, 256, 16, 16, 256, 3, 2, 1, True, False),    # RetinaNet P6: merged classes on the BK=32 kernel
 ]
 
 

@@ -105,6 +105,59 @@ __global__ __launch_bounds__(256) void probe_loop(float* out, const float* __res
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+// Shape comparison on RANDOM operands read from LDS (the chip lowers its clock under MFMA load; the clock it holds can depend
+// on the shape): one wave computes a 32x32 output tile per k-group of 8 either as 4 x v_mfma_f32_32x32x2 (k pairs) or as
+// 2x2 tiles of v_mfma_f32_16x16x4 (2 k-quads): the same FMAs and the same LDS bytes (4 ds_read_b128 per 8 k? see below).
+template <int SHAPE>   // 32 or 16
+__global__ __launch_bounds__(256) void probe_shape(float* out, int iters, float seed) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 64 * 36];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 2 * 64 * 36; i += blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + (unsigned)blockIdx.x * 40503u; h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    lds[i] = (float)(int)(h & 0xFFFF) * (1.f / 65536.f) - 0.5f;
+  }
+  __syncthreads();
+  float s = 0.f;
+  if (SHAPE == 32) {
+    f32x16 acc0, acc1;
+    for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+    const float* As = lds + (lane & 31) * 36 + (lane >> 5) * 4;
+    const float* Bs = As + 64 * 36;
+    for (int it = 0; it < iters; ++it) {          // 16 k per iteration: 8 MFMA 32x32x2
+      const int o = (it & 1) * 16;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + o), b0 = *reinterpret_cast<const f32x4*>(Bs + o);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(As + o + 8), b1 = *reinterpret_cast<const f32x4*>(Bs + o + 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc1, 0, 0, 0);
+      }
+    }
+    for (int e = 0; e < 16; ++e) s += acc0[e] + acc1[e];
+  } else {
+    // 16x16x4: lane l holds A[row l&15][k = l>>4] -> with a b128 read of 4 consecutive k the lane feeds 4 MFMAs whose k sets
+    // are {t, 4+t, 8+t, 12+t}: rows (l&15) + 16*i, k chunk (l>>4)*4 of a 16-wide k group: 2 A reads + 2 B reads per 16 k
+    f32x4 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const float* As = lds + (lane & 15) * 36 + (lane >> 4) * 4;
+    const float* Bs = As + 64 * 36;
+    for (int it = 0; it < iters; ++it) {          // 16 k per iteration: 4 k-quads x 2x2 tiles = 16 MFMA 16x16x4
+      const int o = (it & 1) * 16;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(As + o), a1 = *reinterpret_cast<const f32x4*>(As + 16 * 36 + o);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(Bs + o), b1 = *reinterpret_cast<const f32x4*>(Bs + 16 * 36 + o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+      }
+    }
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 4; ++e) s += acc[i][j][e];
+  }
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 template <typename K>
 void run(const char* name, K kern, int waves, int wg_per_cu, float* out, float seed = 1.0f) {
   const int iters = 20000, blocks = 256 * wg_per_cu;
@@ -130,6 +183,12 @@ int main() {
   R16(1, 4, 1); R16(2, 4, 1); R16(4, 4, 1); R16(1, 4, 4); R16(2, 4, 4); R16(4, 4, 4);
   run("32x32x2 acc=2 lds RANDOM data wg=4w x4", probe32<2, true, 4>, 4, 4, out, 2.0f);
   run("32x32x2 acc=2 lds RANDOM data wg=4w x6", probe32<2, true, 4>, 4, 6, out, 2.0f);
+  for (int rep = 0; rep < 2; ++rep) {
+    run("SHAPE 32x32x2 random LDS operands wg=4w x4", probe_shape<32>, 4, 4, out);
+    run("SHAPE 16x16x4 (2x2) random LDS operands x4", probe_shape<16>, 4, 4, out);
+    run("SHAPE 32x32x2 random LDS operands wg=4w x6", probe_shape<32>, 4, 6, out);
+    run("SHAPE 16x16x4 (2x2) random LDS operands x6", probe_shape<16>, 4, 6, out);
+  }
   float* src; hipMalloc(&src, 64 * 4096 * 16); hipMemset(src, 0, 64 * 4096 * 16);
   for (int g = 4; g <= 6; g += 2) {
     const int iters = 20000, blocks = 256 * g;
