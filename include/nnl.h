@@ -113,9 +113,10 @@ int nnl_conv2d_weight_transpose_multi(const nnl_wt_desc_t* desc, const int32_t* 
                                       double total_elems, void* stream);
 /* dx[N,H,W,C] = sum_{r,s,k} dy[n,(h+pad-r)/stride,(w+pad-s)/stride,k] * wt[c,r,s,k] (integral taps only). */
 size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g);   /* optional workspace, as for the forward */
-/* addend (optional, [N,H,W,C], stride 1 and K % 16 == 0 only): dx = dgrad + addend — the gradient that reaches the block
- * input through the identity shortcut of BasicBlock / Bottleneck (retinanet.py:43-59) is added in the epilogue instead of
- * by a separate autograd accumulation kernel. */
+/* addend (optional, [N,H,W,C]; K % 16 == 0 and stride 1, or a 3x3 / pad 1 filter at stride 2): dx = dgrad + addend — the
+ * gradient that reaches the block input through the shortcut of BasicBlock / Bottleneck (identity, or the input gradient
+ * of the downsample convolution; retinanet.py:43-59,344-348) is added in the epilogue instead of by a separate autograd
+ * accumulation kernel.  A stride-2 dgrad with even H and W runs its four output-parity classes in one launch. */
 int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
                      void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are

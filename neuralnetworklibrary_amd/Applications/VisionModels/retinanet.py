@@ -35,11 +35,12 @@ class HipConv2d(nn.Conv2d):
         super().__init__(*args, **kwargs)
         self.weight.data = self.weight.data.contiguous(memory_format=torch.channels_last)
 
-    def forward(self, x, grad_slot=None):
+    def forward(self, x, grad_slot=None, give_slot=None):
         if self.dilation != (1, 1) or self.groups != 1 or self.stride[0] != self.stride[1] \
                 or self.padding[0] != self.padding[1] or self.padding_mode != 'zeros':
             raise NotImplementedError('HipConv2d: only the symmetric, dense convolutions the reference uses')
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu, grad_slot=grad_slot)
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu, grad_slot=grad_slot,
+                          give_slot=give_slot)
 
 
 class HipMaxPool2d(nn.MaxPool2d):
@@ -77,11 +78,13 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        # identity shortcut: its gradient is added inside conv1's dgrad kernel (ops.GradSlot) instead of by autograd
-        slot = ops.GradSlot() if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        # the shortcut's gradient w.r.t. x is added inside conv1's dgrad kernel (ops.GradSlot) instead of by autograd: the
+        # closing BN parks it there for an identity shortcut, the downsample convolution for a projection shortcut
+        slot = ops.GradSlot() if (x.requires_grad and torch.is_grad_enabled()) else None
         out = ops.conv_bn_act(self.conv1, self.bn1, x, relu=True, conv_slot=slot)
-        residual = x if self.downsample is None else self.downsample(x)
-        return ops.conv_bn_act(self.conv2, self.bn2, out, residual=residual, relu=True, bn_slot=slot)
+        if self.downsample is None:
+            return ops.conv_bn_act(self.conv2, self.bn2, out, residual=x, relu=True, bn_slot=slot)
+        return ops.conv_bn_act(self.conv2, self.bn2, out, residual=_shortcut(self.downsample, x, slot), relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -101,18 +104,24 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        slot = ops.GradSlot() if (self.downsample is None and x.requires_grad and torch.is_grad_enabled()) else None
+        slot = ops.GradSlot() if (x.requires_grad and torch.is_grad_enabled()) else None
         out = ops.conv_bn_act(self.conv1, self.bn1, x, relu=True, conv_slot=slot)
         out = ops.conv_bn_act(self.conv2, self.bn2, out, relu=True)
-        residual = x if self.downsample is None else self.downsample(x)
-        return ops.conv_bn_act(self.conv3, self.bn3, out, residual=residual, relu=True, bn_slot=slot)
+        if self.downsample is None:
+            return ops.conv_bn_act(self.conv3, self.bn3, out, residual=x, relu=True, bn_slot=slot)
+        return ops.conv_bn_act(self.conv3, self.bn3, out, residual=_shortcut(self.downsample, x, slot), relu=True)
 
 
 class _Downsample(nn.Sequential):
     "Sequential(conv1x1(stride), BN) (retinanet.py:344-348) evaluated with the fused BN epilogue"
 
-    def forward(self, x):
-        return ops.conv_bn_act(self[0], self[1], x, relu=False)
+    def forward(self, x, give_slot=None):
+        return ops.conv_bn_act(self[0], self[1], x, relu=False, conv_give=give_slot)
+
+
+def _shortcut(downsample, x, slot):
+    "projection shortcut; a _Downsample hands its input gradient to the block's first conv through `slot`"
+    return downsample(x, give_slot=slot) if isinstance(downsample, _Downsample) else downsample(x)
 
 
 class PyramidFeatures(nn.Module):

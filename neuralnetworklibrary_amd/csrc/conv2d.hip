@@ -611,8 +611,10 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
   NNL_CHECK_ARG(g->K % 4 == 0, "conv2d_dgrad: K=%d must be a multiple of 4", g->K);
   {
     const bool taps = taps_ok((long)g->N * g->P * g->Q * g->K, (long)g->C * g->R * g->S * g->K, g->K, g->R * g->S);
-    if (addend != nullptr && !(taps && g->stride == 1))
-      return nnl_set_error(NNL_ERR_UNSUPPORTED, "conv2d_dgrad: the fused addend needs stride 1 and K %% 16 == 0");
+    // stride 2: the addend is applied by the class that owns each dx pixel, so every output-parity class needs a tap (3x3, pad 1)
+    const bool s2_full = g->stride == 2 && g->R == 3 && g->S == 3 && g->pad == 1;
+    if (addend != nullptr && !(taps && (g->stride == 1 || s2_full)))
+      return nnl_set_error(NNL_ERR_UNSUPPORTED, "conv2d_dgrad: the fused addend needs K %% 16 == 0 and stride 1 (or a 3x3 / pad 1 filter at stride 2)");
   }
   hipStream_t s = (hipStream_t)stream;
   IgemmRowkParams p{};

@@ -190,11 +190,16 @@ class GradSlot:
     its identity shortcut here (instead of returning it to autograd) and the block's FIRST convolution adds it in the
     epilogue of its dgrad kernel — one accumulation kernel and three tensor passes less per block.  Valid because the first
     convolution's backward always runs after the closing BN's backward (it depends on it through the main path) and both
-    consume the same tensor x."""
-    __slots__ = ('tensor',)
+    consume the same tensor x.
+    A block with a projection shortcut uses it the same way: the downsample convolution (`give_slot`) parks ITS input gradient
+    here and returns none to autograd.  There is no dependency between the two convolutions' backward nodes (the engine runs
+    the later-created downsample first), so the hand-over is guarded: the consumer closes the slot when it runs, and a
+    producer that finds it closed returns its gradient to autograd as usual."""
+    __slots__ = ('tensor', 'closed')
 
     def __init__(self):
         self.tensor = None
+        self.closed = False
 
 
 class _Conv2d(torch.autograd.Function):
@@ -202,9 +207,10 @@ class _Conv2d(torch.autograd.Function):
     241-257,304,345) on the fp32-MFMA implicit-GEMM kernels; optional fused bias + ReLU epilogue."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, relu, slot=None, bn_pivot=None):
+    def forward(ctx, x, weight, bias, stride, pad, relu, slot=None, bn_pivot=None, give_slot=None):
         require_cuda(x, weight, bias)
         ctx.slot = slot
+        ctx.give_slot = give_slot
         ctx.grad_dst = getattr(weight, '_nnl_grad_dst', None)     # data parallel: the flat all-reduce bucket (dist.GradSync)
         xn = _pad_c4(to_nhwc(_f32c(x) if x.dim() != 4 else x.float()))
         wn = _pad_c4(to_nhwc(weight.float()))
@@ -234,7 +240,7 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dpart=None):
         if dy is None:
-            return (None,) * 8
+            return (None,) * 9
         xn, wn, y = ctx.saved_tensors
         g = ctx.g
         dyn = to_nhwc(dy.float())
@@ -256,15 +262,21 @@ class _Conv2d(torch.autograd.Function):
             dws = torch.empty(wsb // 4, dtype=torch.float32, device=dyn.device) if wsb else None
             shortcut = None
             if ctx.slot is not None:
-                shortcut, ctx.slot.tensor = ctx.slot.tensor, None
-            fuse = shortcut is not None and g.stride == 1 and g.K % 16 == 0 and shortcut.numel() == dxn.numel()
+                shortcut, ctx.slot.tensor, ctx.slot.closed = ctx.slot.tensor, None, True
+            # stride 2: every output-parity class of a 3x3 / pad 1 filter has a tap, so every dx pixel passes through the epilogue
+            fuse = shortcut is not None and g.K % 16 == 0 and shortcut.numel() == dxn.numel() \
+                and (g.stride == 1 or (g.stride == 2 and g.R == 3 and g.S == 3 and g.pad == 1))
             check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
                                        ptr(_tile_counters(dyn.device) if wsb else None), stream()))
             if shortcut is not None and not fuse:
                 dxn += shortcut.view_as(dxn)
-            dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
+            give = ctx.give_slot
+            if give is not None and not give.closed and ctx.c_in == g.C:
+                give.tensor = dxn                           # the block's first conv adds it inside its dgrad kernel
+            else:
+                dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
         elif ctx.slot is not None:
-            ctx.slot.tensor = None
+            ctx.slot.tensor, ctx.slot.closed = None, True
         if ctx.needs_input_grad[1]:
             dst = ctx.grad_dst
             if dst is not None and dst.dim() == 4 and g.K == K and ctx.c_in == g.C and dst.permute(0, 2, 3, 1).is_contiguous() \
@@ -282,19 +294,19 @@ class _Conv2d(torch.autograd.Function):
             cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device)
             check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, ptr(cws), cb, stream()))
             db = db_full[:K]
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, grad_slot=None):
+def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, grad_slot=None, give_slot=None):
     """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S].
     grad_slot: see GradSlot (the shortcut gradient of a residual block, added to dx inside the dgrad kernel)."""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu), grad_slot, None)[0]
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu), grad_slot, None, give_slot)[0]
 
 
-def conv2d_with_bn_stats(x, weight, bias, stride, pad, bn_pivot, grad_slot=None):
+def conv2d_with_bn_stats(x, weight, bias, stride, pad, bn_pivot, grad_slot=None, give_slot=None):
     """conv2d whose epilogue also reduces the BatchNorm batch statistics of its output against `bn_pivot` [K].  Returns (y, partials);
     partials is empty when this launch could not produce them (the BatchNorm then runs its own statistics pass)."""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), False, grad_slot, bn_pivot)
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), False, grad_slot, bn_pivot, give_slot)
 
 
 def linear(x, weight, bias=None, relu=False):
@@ -496,7 +508,7 @@ class _ConcatPool(torch.autograd.Function):
         return from_nhwc(dx)
 
 
-def conv_bn_act(conv, bn, x, residual=None, relu=True, conv_slot=None, bn_slot=None):
+def conv_bn_act(conv, bn, x, residual=None, relu=True, conv_slot=None, bn_slot=None, conv_give=None):
     """bn_act(bn, conv(x), residual, relu) for a HipConv2d followed by BatchNorm — the conv -> bn -> (+shortcut) -> relu unit of the
     ResNet blocks (retinanet.py:43-59,77-97,304-306).  In training mode the convolution's epilogue reduces the batch statistics
     as shifted sums sum(y - pivot), sum((y - pivot)^2), so the BatchNorm does not re-read the activation for them.  The pivot is
@@ -507,15 +519,15 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, conv_slot=None, bn_slot=N
             and getattr(bn, 'nnl_sync', None) is None and x.is_cuda and conv.bias is None and not conv.fuse_relu
             and torch.is_grad_enabled() and os.environ.get('NNL_BN_EPI_STATS', '1') != '0')
     if not fuse:
-        return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot)
+        return bn_act(bn, conv(x, grad_slot=conv_slot, give_slot=conv_give), residual=residual, relu=relu, grad_slot=bn_slot)
     pivot = getattr(bn, '_nnl_pivot', None)
     if pivot is None or pivot.device != x.device or pivot.numel() != bn.num_features:
         if torch.cuda.is_current_stream_capturing():
-            return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot)
+            return bn_act(bn, conv(x, grad_slot=conv_slot, give_slot=conv_give), residual=residual, relu=relu, grad_slot=bn_slot)
         pivot = torch.empty(bn.num_features, dtype=torch.float32, device=x.device)
         object.__setattr__(bn, '_nnl_pivot', pivot)                  # plain attribute: not a buffer, not in the state_dict
-        return bn_act(bn, conv(x, grad_slot=conv_slot), residual=residual, relu=relu, grad_slot=bn_slot, pivot_out=pivot)
-    y, part = conv2d_with_bn_stats(x, conv.weight, None, conv.stride[0], conv.padding[0], pivot, conv_slot)
+        return bn_act(bn, conv(x, grad_slot=conv_slot, give_slot=conv_give), residual=residual, relu=relu, grad_slot=bn_slot, pivot_out=pivot)
+    y, part = conv2d_with_bn_stats(x, conv.weight, None, conv.stride[0], conv.padding[0], pivot, conv_slot, conv_give)
     return bn_act(bn, y, residual=residual, relu=relu, grad_slot=bn_slot, ext_stats=(part, pivot), pivot_out=pivot)
 
 
