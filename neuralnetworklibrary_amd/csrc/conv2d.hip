@@ -378,33 +378,43 @@ int colsum_chunks(long rows) {
 
 struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split; };
 
+// Tile AND split count are searched together for the shortest predicted launch: all workgroups are resident at once
+// (occupancy 4-5), so a launch lasts ceil(blocks/256) x (pixels per split) x (time per workgroup-pixel of the tile); rounding
+// k_per_split to 32 and a short last split are accounted for by using the real split length; fewer than 4 workgroups per CU
+// cannot hide the load latency; the slab reduce moves (splits+1) x |dw| bytes.  The smaller tiles pay a measured
+// efficiency factor (bench_conv.py, NNL_WGRAD_TILE sweep) but give short pixel ranges (1x1/2 shortcut convs: 12544 pixels)
+// enough workgroups to fill 256 CUs.
 WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
-  WgradPlan pl;
-  const char* e_wt = getenv("NNL_WGRAD_TILE"); const int forced = e_wt ? atoi(e_wt) : -1;   // tuning hook (re-read per call)
-  pl.bm = (Mc >= 128) ? 128 : 64;
-  pl.bn = (Nc >= 128 && pl.bm == 128) ? 128 : 64;
-  if (forced == 0) { pl.bm = 128; pl.bn = 128; } else if (forced == 1) { pl.bm = 128; pl.bn = 64; } else if (forced == 3) { pl.bm = 64; pl.bn = 64; }
-  pl.grid_m = (int)nnl_cdiv(Mc, pl.bm);
-  pl.grid_n = (int)nnl_cdiv(Nc, pl.bn);
-  const long tiles = (long)pl.grid_m * pl.grid_n;
-  const long max_splits = Kp / 256 > 0 ? Kp / 256 : 1;    // at least 256 pixels (16 k-steps) per split
-  // Search the split count around ~4 workgroups per CU for the shortest busiest-CU time: all workgroups are resident at
-  // once (occupancy 5), so the launch lasts ceil(blocks/256) x (pixels per split); rounding k_per_split to 32 and a short
-  // last split are accounted for by using the real split length.  The slab reduce costs (2*splits+1) x |dw| bytes.
-  long splits = 1, kps = nnl_cdiv(Kp, 32) * 32;
+  struct Cand { int bm, bn; double cost; };                               // cost: time per FLOP relative to the 128x128 tile
+  static const Cand cands[4] = {{128, 128, 1.00}, {128, 64, 1.08}, {64, 128, 1.08}, {64, 64, 1.10}};
+  const int forced = os_env_int("NNL_WGRAD_TILE", -1);                    // tuning hook (re-read per call): index into cands
+  const long max_splits = Kp / 256 > 0 ? Kp / 256 : 1;                    // at least 256 pixels (16 k-steps) per split
+  WgradPlan pl{};
   double best_t = 1e300;
-  const double us_per_px = (double)pl.bm * pl.bn * 2.0 / 441e3;            // one workgroup-pixel at ~113 TF/s / 256 CUs
-  for (long sp = 1; sp <= max_splits && tiles * sp <= 256 * 5; ++sp) {
-    const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32) * 32;
-    const long rs = nnl_cdiv(Kp, k1);
-    if (rs != sp) continue;                                               // same plan as a smaller sp
-    const long per_cu = nnl_cdiv(tiles * rs, 256);
-    const double starve = per_cu < 4 ? pow(4.0 / per_cu, 0.3) : 1.0;      // < 4 workgroups per CU cannot hide the load latency
-    const double t = (double)per_cu * k1 * us_per_px * starve + (rs > 1 ? (2.0 * rs + 1) * Mc * Nc * 4 / 3.0e6 + 3 : 0);
-    if (t < best_t) { best_t = t; splits = rs; kps = k1; }
+  for (int ci = 0; ci < 4; ++ci) {
+    const Cand& c = cands[ci];
+    if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
+    const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
+    const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
+    for (long sp = 1; sp <= max_splits && tiles * sp <= 256 * 5; ++sp) {
+      const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32) * 32;
+      const long rs = nnl_cdiv(Kp, k1);
+      if (rs != sp) continue;                                             // same plan as a smaller sp
+      const long per_cu = nnl_cdiv(tiles * rs, 256);
+      const double starve = per_cu < 4 ? pow(4.0 / per_cu, 0.3) : 1.0;
+      const double t = (double)per_cu * k1 * us_per_px * starve + (rs > 1 ? (rs + 1.0) * Mc * Nc * 4 / 4.5e6 + 3 : 0);   // reduce: rs slab reads + one write at ~4.5 TB/s
+      if (t < best_t) {
+        best_t = t;
+        pl.bm = c.bm; pl.bn = c.bn; pl.grid_m = (int)nnl_cdiv(Mc, c.bm); pl.grid_n = (int)nnl_cdiv(Nc, c.bn);
+        pl.splits = (int)rs; pl.k_per_split = (int)k1;
+      }
+    }
   }
-  pl.splits = (int)splits;
-  pl.k_per_split = (int)kps;
+  if (pl.bm == 0) {                                                       // more tiles than 5 per CU even unsplit: largest legal tile
+    pl.bm = Mc >= 128 ? 128 : 64; pl.bn = (Nc >= 128 && pl.bm == 128) ? 128 : 64;
+    pl.grid_m = (int)nnl_cdiv(Mc, pl.bm); pl.grid_n = (int)nnl_cdiv(Nc, pl.bn);
+    pl.splits = 1; pl.k_per_split = (int)(nnl_cdiv(Kp, 32) * 32);
+  }
   return pl;
 }
 
@@ -422,8 +432,7 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   q.Mc = Mc; q.Nc = Nc; q.Kp = (int)Kp;
   q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
-  const char* e_bk = getenv("NNL_WGRAD_BK32");                       // tuning hook
-  const int bk32 = e_bk ? atoi(e_bk) : 0;
+  const int bk32 = os_env_int("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
   const char* e_pipe = getenv("NNL_WGRAD_PIPE");                     // A/B hook: 1 = software-pipelined fragment reads
   const int pipe = e_pipe ? atoi(e_pipe) : 1;
   if (pl.bm == 128 && pl.bn == 128) {
@@ -431,6 +440,8 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
     else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);   // BK=32 measured -7 % here
   } else if (pl.bm == 128) {
     hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, q);
+  } else if (pl.bn == 128) {
+    hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 16, 2, 2, true>), grid, block, 0, s, q);
   } else {
     if (bk32 && pl.k_per_split % 32 == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2>), grid, block, 0, s, q);
     else if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2, true>), grid, block, 0, s, q);
@@ -519,6 +530,8 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
       hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
     else if (pl.bm == 128)
       hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
+    else if (pl.bn == 128)
+      hipLaunchKernelGGL((igemm_kmajor_kernel<64, 128, 16, 2, 2>), grid, block, 0, s, p);
     else
       hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
     NNL_CHECK_LAUNCH();
@@ -733,6 +746,8 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
       hipLaunchKernelGGL((igemm_kmajor_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, p);
     else if (pl.bm == 128)
       hipLaunchKernelGGL((igemm_kmajor_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, p);
+    else if (pl.bn == 128)
+      hipLaunchKernelGGL((igemm_kmajor_kernel<64, 128, 16, 2, 2>), grid, block, 0, s, p);
     else
       hipLaunchKernelGGL((igemm_kmajor_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, p);
     NNL_CHECK_LAUNCH();
