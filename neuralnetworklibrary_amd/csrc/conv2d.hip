@@ -56,6 +56,15 @@ int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
 
 static int os_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }   // A/B hooks, re-read per call
 
+// LDS-DMA staging of the 64x64 tile (igemm_taps.h): an experiment kept behind NNL_IGEMM_DMA (0 off = default, 1 BK=16 launches,
+// 2 BK=32 launches, 3 both).  Measured per ResNet-34 layer (bench_conv.py --ab NNL_IGEMM_DMA=0,3): +3.5 % on the 56x56 / C=64
+// stage, -1 % on 28x28 / C=128, -7 % with BK=32 (two buffers); inside the full training step the gain on the C=64 stage
+// does not show (15.44 ms/step either way), so register staging stays the shipped path.
+static bool taps_dma(int bk, const IgemmTapsParams&) {
+  const int m = os_env_int("NNL_IGEMM_DMA", 0);
+  return bk == 16 ? (m & 1) != 0 : (m & 2) != 0;
+}
+
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
   { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
@@ -63,6 +72,13 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
   p.cls_tiles = p.grid_m * p.grid_n;
   const unsigned gx = (unsigned)(p.grid_m * p.grid_n * (p.ncls > 1 ? p.ncls : 1));
+  if constexpr (BM == 64 && BN == 64) {
+    if (taps_dma(BK, p)) {
+      hipLaunchKernelGGL((igemm_taps_kernel<64, 64, BK, 2, 2, false, 0, true>), dim3(gx, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+      NNL_CHECK_LAUNCH();
+      return NNL_OK;
+    }
+  }
   if (BM == 64 && BN == 64 && p.variant == 1)
     hipLaunchKernelGGL((igemm_taps_kernel<BM, BN, BK, 2, 2, true>), dim3(gx, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
   else
@@ -175,6 +191,10 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counte
   const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
   if (pl.bm == 128)
     hipLaunchKernelGGL((igemm_taps_kernel<128, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk == 32 && taps_dma(32, p))
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk != 32 && taps_dma(16, p))
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk == 32 && p.variant == 1)
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk == 32)

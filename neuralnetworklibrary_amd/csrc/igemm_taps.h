@@ -97,11 +97,20 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
 
 __device__ __forceinline__ float nnl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0>
+// DMA = true (64x64 tile, EPI 0): the operand tiles go global -> LDS directly (`buffer_load_dwordx4 ... lds`, LDS-DMA) instead
+// of through VGPRs and ds_write_b128.  An LDS-DMA wave-instruction writes 64 x 16 B lane-linear (wave-uniform base + lane*16),
+// so the LDS image is UNPADDED [row][BK]; bank conflicts of the ds_read_b128 fragment reads are avoided by an XOR swizzle of
+// the 16-B chunk index with row bits, applied on the SOURCE side (which chunk a lane fetches) and again by the reader.
+// Three LDS buffers keep one tile in flight across the barrier (counted vmcnt, raw s_barrier).
+#define NNL_LDSP(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0, bool DMA = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
   static_assert(EPI == 0 || (BM == 64 && BN == 64), "the LSTM epilogue is written for the 64x64 tile");
   static_assert(WGM * WGN == 4 && BK % 8 == 0, "config");
-  constexpr int BKP = BK + 4;
+  static_assert(!DMA || (BM == 64 && BN == 64 && EPI == 0 && (BK == 16 || BK == 32)), "LDS-DMA staging: 64x64 tile only");
+  constexpr int BKP = DMA ? BK : BK + 4;
+  constexpr int NBUF = (DMA && BK == 16) ? 3 : 2;      // BK=32: three 16 KB... 48 KB of LDS would cost a workgroup per CU
   constexpr int KC = BK / 4;
   constexpr int RPP = 256 / KC;
   constexpr int PA = BM / RPP, PB = BN / RPP;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
 
-  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BKP];
+  __shared__ __attribute__((aligned(16))) float lds[NBUF][(BM + BN) * BKP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
@@ -149,6 +158,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   const int tile_m = logical / p.grid_n, tile_n = logical - tile_m * p.grid_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kc = tid % KC, lrow = tid / KC;
+  // staging map: pass i of this thread covers tile row srow(i) and fetches 16-B chunk schunk(i) of that row
+  auto swz = [](int row) { return BK == 16 ? (row >> 2) & 3 : (row >> 1) & 7; };     // DMA image: chunk' = chunk ^ swz(row)
+  auto srow = [&](int i) { return DMA ? (wave * PA + i) * (64 / KC) + lane / KC : lrow + i * RPP; };
+  auto schunk = [&](int i) { return DMA ? (lane % KC) ^ swz(srow(i)) : kc; };
 
   const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   const int PQ = p.P * p.Q;
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int m = m0 + lrow + i * RPP;
+    const int m = m0 + srow(i);
     const bool valid = m < p.M;
     const int mm = valid ? m : 0;
     const int n = mm / PQ;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     const int pp = rem / p.Q;
     const int qq = rem - pp * p.Q;
     const int h0 = pp * p.in_stride + p.ih0, w0 = qq * p.in_stride + p.iw0;
-    a_off[i] = (((n * p.H + h0) * p.W + w0) * p.C + kc * 4) * 4;
+    a_off[i] = (((n * p.H + h0) * p.W + w0) * p.C + schunk(i) * 4) * 4;
     unsigned long long mask = 0;
     if (valid)
       for (int t = 0; t < ntaps; ++t) {
@@ -179,14 +192,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   unsigned b_off[PB];
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    int nr = n0 + lrow + i * RPP;
+    int nr = n0 + srow(i);
     bool okr = nr < p.Nc;
     if constexpr (EPI == 1) {                      // gate-gathered rows: (gate, unit) -> W_hh row gate*H + unit
       const int nl = lrow + i * RPP, u = tile_n * 16 + (nl & 15);
       okr = u < p.lstm.H;
       nr = (nl >> 4) * p.lstm.H + u;
     }
-    b_off[i] = okr ? (unsigned)(nr * p.b_row_stride + kc * 4) * 4u : 0xFFFFFFFFu;
+    b_off[i] = okr ? (unsigned)(nr * p.b_row_stride + schunk(i) * 4) * 4u : 0xFFFFFFFFu;
   }
 
   f32x4 ra[PA], rb[PB];
@@ -201,13 +214,24 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 #pragma unroll
     for (int i = 0; i < PA; ++i) a_voff[i] = ((a_mask[i] >> t) & 1ull) ? (unsigned)(a_off[i] + a_tap) : 0xFFFFFFFFu;
   };
-  auto load_tile = [&](int c0) {
+  auto load_tile = [&](int c0, int buf) {
+    if constexpr (DMA) {
+      // piece (wave, i) = 64 consecutive 16-B slots of the A image (rows (wave*PA+i)*(64/KC) ...) and the same of the B image
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, a_voff[i], (unsigned)c0 * 4u);
+      for (int i = 0; i < PA; ++i) {
+        float* dst = lds[buf] + (wave * PA + i) * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_src, NNL_LDSP(dst), 16, (int)a_voff[i], c0 * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, NNL_LDSP(dst + BM * BK), 16, (int)b_off[i], (int)b_tap + c0 * 4, 0, 0);
+      }
+    } else {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, b_off[i], b_tap + (unsigned)c0 * 4u);
+      for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, a_voff[i], (unsigned)c0 * 4u);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, b_off[i], b_tap + (unsigned)c0 * 4u);
+    }
   };
   auto store_tile = [&](int buf) {
+    if constexpr (DMA) return;
     float* As = lds[buf];
     float* Bs = As + BM * BKP;
 #pragma unroll
@@ -231,7 +255,35 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   f32x16 acc2;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+  // DMA image: fragment chunk (kk*2 + k half) of row r lives at chunk' = chunk ^ swz(r): per-lane float offsets per 8-wide k group
+  int fa_off[BK / 8], fb_off[BK / 8];
+  if constexpr (DMA) {
+    const int ra_r = wm * 32 + (lane & 31), rb_r = wn * 32 + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) {
+      fa_off[kk] = ra_r * BK + (((kk * 2 + (lane >> 5)) ^ swz(ra_r)) * 4);
+      fb_off[kk] = BM * BK + rb_r * BK + (((kk * 2 + (lane >> 5)) ^ swz(rb_r)) * 4);
+    }
+  }
   auto compute = [&](int buf) {
+    if constexpr (DMA) {
+      const float* base = lds[buf];
+      f32x4 fa[BK / 8], fb[BK / 8];
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        fa[kk] = *reinterpret_cast<const f32x4*>(base + fa_off[kk]);
+        fb[kk] = *reinterpret_cast<const f32x4*>(base + fb_off[kk]);
+      }
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; kk += 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][t], fb[kk][t], acc[0][0], 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk + 1][t], fb[kk + 1][t], acc2, 0, 0, 0);
+        }
+      }
+      return;
+    }
     const float* As = lds[buf] + wm * WTM * BKP + frag_off;
     const float* Bs = lds[buf] + BM * BKP + wn * WTN * BKP + frag_off;
     if constexpr (kTwoAcc) {
@@ -298,26 +350,76 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     if (nk < 0) nk = 0;
   }
   int t_nx = kt0 / csteps, c_nx = (kt0 - t_nx * csteps) * BK;       // (tap, c0) of the NEXT tile to fetch
+  auto advance = [&]() {                       // (t_nx, c_nx) -> the next k tile; refreshes the per-tap state at a tap boundary
+    c_nx += BK;
+    if (c_nx >= p.C) { c_nx = 0; ++t_nx; set_tap(t_nx); }        // wave-uniform branch, once per tap
+  };
+  if constexpr (DMA && NBUF == 3) {
+    // three LDS buffers, tile kt+2 issued while tile kt is computed; before the barrier that ends iteration kt every wave
+    // waits until ITS pieces of tile kt+1 have landed (all but the 2*PA youngest DMAs = those of tile kt+2), so after the
+    // barrier tile kt+1 is complete; buffer (kt+2)%3 was last read in iteration kt-1, which every wave has left.
+    static_assert(PA == 1, "vmcnt immediate below");
+    if (nk > 0) {
+      set_tap(t_nx);
+      load_tile(c_nx, 0);
+      if (nk > 1) advance();
+      load_tile(c_nx, 1);                      // nk == 1: re-fetches tile 0 (never read)
+    }
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) advance();              // the last two iterations re-fetch the last tile (never read; keeps the body uniform)
+      int nx2 = cur + 2; if (nx2 >= 3) nx2 -= 3;
+      load_tile(c_nx, nx2);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the spare fetches before the epilogue reuses the LDS
+    __syncthreads();
+  } else if constexpr (DMA) {
+    // two LDS buffers: tile kt+1 streams in while tile kt is computed; drained before the barrier
+    if (nk > 0) {
+      set_tap(t_nx);
+      load_tile(c_nx, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) advance();
+      load_tile(c_nx, cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur ^= 1;
+    }
+    __syncthreads();
+  } else {
   if (nk > 0) {
     set_tap(t_nx);
-    load_tile(c_nx);
+    load_tile(c_nx, 0);
     store_tile(0);
   }
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // advance to tile kt+1 (the final iteration re-fetches the last tile instead: harmless, keeps the body uniform)
-    if (kt + 1 < nk) {
-      c_nx += BK;
-      if (c_nx >= p.C) { c_nx = 0; ++t_nx; set_tap(t_nx); }      // wave-uniform branch, once per tap
-    }
-    load_tile(c_nx);                           // buffer loads of tile kt+1 go out FIRST ...
+    if (kt + 1 < nk) advance();
+    load_tile(c_nx, 0);                        // buffer loads of tile kt+1 go out FIRST ...
     __builtin_amdgcn_sched_barrier(0);         // ... (keep the compiler from sinking them behind the MFMAs to save VGPRs)
     compute(cur);                              // 32 MFMAs per wave cover their latency
     __builtin_amdgcn_sched_barrier(0);
     store_tile(cur ^ 1);                       // vmcnt wait + ds_write only after the MFMAs are issued
     __syncthreads();
     cur ^= 1;
+  }
   }
 
   // ---- epilogue ----
