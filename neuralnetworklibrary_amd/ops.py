@@ -145,8 +145,12 @@ def prepare_backward(model):
     """Call right before `loss.backward()` (Learner does): transposes the filters of every HipConv2d of `model` in ONE launch
     (one small launch per layer otherwise) and exposes them to the convolutions' backward until finish_backward().  The
     window is deliberately that short: a filter modified later can never meet a stale transpose."""
-    ws = [m.weight for m in model.modules()
-          if getattr(m, 'nnl_hip_conv', False) and m.weight.is_cuda and m.weight.dim() == 4 and m.weight.shape[1] % 4 == 0
+    mods = getattr(model, '_nnl_conv_mods', None)
+    if mods is None:                # the module walk costs ~0.1 ms per step on a host-bound model: done once.  A conv added
+        mods = [m for m in model.modules() if getattr(m, 'nnl_hip_conv', False)]     # later transposes its own filter (slower, correct)
+        object.__setattr__(model, '_nnl_conv_mods', mods)
+    ws = [m.weight for m in mods
+          if m.weight.is_cuda and m.weight.dim() == 4 and m.weight.shape[1] % 4 == 0
           and m.weight.shape[0] % 4 == 0 and m.weight.dtype == torch.float32
           and m.weight.is_contiguous(memory_format=torch.channels_last)]
     if len(ws) < 2 or sum(w.requires_grad for w in ws) * 2 < len(ws):
