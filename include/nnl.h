@@ -156,6 +156,25 @@ int nnl_bn_bwd(const float* dy, const float* y, const uint32_t* relu_mask, const
                const float* mean, const float* invstd, float* dx, float* dres, float* dgamma, float* dbeta, int64_t rows,
                int64_t C, int training, int relu, void* workspace, size_t workspace_bytes, void* stream);
 
+/* BatchNorm -> ReLU -> MaxPool2d(ks, stride, pad) in one pass: the ResNet stem (reference retinanet.py:372-374, torchvision's
+ * bn1 / relu / maxpool).  x [N,H,W,C] is the convolution output; y [N,P,Q,C] the pooled activation, idx [N,P,Q,C] the window
+ * position (kh*ks + kw) of each maximum (torch's tie rule); the normalised activation itself is never written.  save_scale /
+ * save_shift [C] receive the per-channel affine (the backward recomputes its ReLU gate from them); statistics, running-stat
+ * update and num_batches_tracked as nnl_bn_fwd.  C % 4 == 0 and C/4 dividing 256 (nnl_bn_relu_maxpool_supported).
+ * Workspace: nnl_bn_workspace_bytes(N*H*W, C). */
+int nnl_bn_relu_maxpool_supported(int64_t C);
+int nnl_bn_relu_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* y, uint8_t* idx, float* save_mean,
+                            float* save_invstd, float* save_scale, float* save_shift, float* running_mean, float* running_var,
+                            int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t Q, int ks, int stride, int pad, float eps,
+                            float momentum, int training, int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
+                            void* stream);
+/* dx [N,H,W,C], dgamma, dbeta from the pooled gradient dpool [N,P,Q,C]: every input pixel gathers dpool over the windows whose
+ * arg-max it is (no atomics: reproducible), gated by the recomputed ReLU, then the two BatchNorm backward passes. */
+int nnl_bn_relu_maxpool_bwd(const float* dpool, const uint8_t* idx, const float* x, const float* gamma, const float* mean,
+                            const float* invstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                            int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t Q, int ks, int stride, int pad,
+                            int training, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Cross-replica (synchronised) training-mode BatchNorm for data parallelism (global-batch statistics equal
  * to the single-GPU reference's).  Split-phase, the host runs the collective in between (neuralnetworklibrary_amd/ops.py):
  *   fwd:  nnl_bn_sync_stats -> all_gather of `stats` (2C+2 floats per rank) -> nnl_bn_sync_fwd

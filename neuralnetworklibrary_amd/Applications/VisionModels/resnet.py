@@ -44,7 +44,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward(self, x):
-        x = self.maxpool(ops.conv_bn_act(self.conv1, self.bn1, x, relu=True))
+        x = ops.conv_bn_relu_maxpool(self.conv1, self.bn1, self.maxpool, x)
         x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
         x = self.avgpool(x).flatten(1)
         return ops.linear(x, self.fc.weight, self.fc.bias, relu=False)
@@ -56,7 +56,11 @@ class ResNetBody(nn.Sequential):
 
     def forward(self, x):
         mods = list(self.children())
-        if len(mods) >= 3 and isinstance(mods[0], HipConv2d) and isinstance(mods[1], nn.BatchNorm2d) \
+        if len(mods) >= 4 and isinstance(mods[0], HipConv2d) and isinstance(mods[1], nn.BatchNorm2d) \
+                and isinstance(mods[2], nn.ReLU) and isinstance(mods[3], nn.MaxPool2d):
+            x = ops.conv_bn_relu_maxpool(mods[0], mods[1], mods[3], x)          # BN + ReLU + pooling in one pass
+            mods = mods[4:]
+        elif len(mods) >= 3 and isinstance(mods[0], HipConv2d) and isinstance(mods[1], nn.BatchNorm2d) \
                 and isinstance(mods[2], nn.ReLU):
             x = ops.conv_bn_act(mods[0], mods[1], x, relu=True)
             mods = mods[3:]

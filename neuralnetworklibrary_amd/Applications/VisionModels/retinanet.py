@@ -255,7 +255,7 @@ class RetinaNet(nn.Module):
         return nn.Sequential(*layers)
 
     def stem(self, x):
-        return self.maxpool(ops.conv_bn_act(self.conv1, self.bn1, x, relu=True))
+        return ops.conv_bn_relu_maxpool(self.conv1, self.bn1, self.maxpool, x)
 
     def forward(self, img_batch):
         x = self.stem(img_batch)

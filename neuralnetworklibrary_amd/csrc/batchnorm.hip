@@ -605,6 +605,230 @@ extern "C" int nnl_bn_bwd(const float* dy, const float* y, const uint32_t* relu_
   return NNL_OK;
 }
 
+// ---- BatchNorm -> ReLU -> MaxPool2d in one pass (the ResNet stem: reference retinanet.py:372-374) -----------------------------
+// The normalised, rectified activation z = relu(scale*x + shift) is never written: the forward pools it on the fly (torch's tie
+// rule: first maximum in (kh, kw) scan order, NaN propagates) and keeps the uint8 window index; the backward re-derives, for
+// every input pixel, g = [z > 0] * sum of dpool over the windows whose arg-max it is (a gather: no atomics), recomputing z with
+// the forward's arithmetic, and feeds g to the usual two BatchNorm backward passes.  Against bn_apply + maxpool_fwd and
+// maxpool_bwd + bn_bwd this saves writing and re-reading the [N,H,W,C] activation (forward) and its gradient (backward):
+// ~12 + 16 bytes per pre-pool element.
+namespace {
+
+__device__ __forceinline__ f32x4 bnpool_affine(const f32x4& x, const f32x4& sc, const f32x4& sh) {
+  f32x4 z;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) z[e] = x[e] * sc[e] + sh[e];       // same expression as bn_apply_kernel (-ffp-contract=off)
+  return z;
+}
+
+__global__ __launch_bounds__(kBlock) void bnpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, float* __restrict__ y,
+                                                            uint8_t* __restrict__ idx, int N, int H, int W, int C4, int P, int Q,
+                                                            int ks, int stride, int pad) {
+  // one thread = one OUTPUT pixel x 4 channels; the grid stride is a multiple of C4, so a thread keeps its channels
+  const long total = (long)N * P * Q * C4;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = (int)(i0 % C4);
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C4;
+    const int q = (int)(r % Q); r /= Q;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    f32x4 best = {0.f, 0.f, 0.f, 0.f};
+    int bi[4] = {-1, -1, -1, -1};
+    for (int kh = 0; kh < ks; ++kh) {
+      const int h = p * stride - pad + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < ks; ++kw) {
+        const int w = q * stride - pad + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        f32x4 v = bnpool_affine(reinterpret_cast<const f32x4*>(x)[((long)(n * H + h) * W + w) * C4 + c4], sc, sh);
+        const int t = kh * ks + kw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (v[e] != v[e]) ? v[e] : fmaxf(v[e], 0.f);            // ReLU (NaN stays NaN, as torch.relu)
+          if (bi[e] < 0 || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = t; }
+        }
+      }
+    }
+    reinterpret_cast<f32x4*>(y)[i] = best;
+    reinterpret_cast<uchar4*>(idx)[i] = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
+  }
+}
+
+struct PoolGeom { int H, W, C4, P, Q, ks, stride, pad; };
+
+// g for input element (n, h, w, c4): gathered pooled gradient, gated by the recomputed ReLU
+__device__ __forceinline__ f32x4 bnpool_grad(const float* __restrict__ dpool, const uint8_t* __restrict__ idx, const f32x4& xv,
+                                             const f32x4& sc, const f32x4& sh, int n, int h, int w, int c4, const PoolGeom& g) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int p_lo = h + g.pad - g.ks + 1; p_lo = p_lo > 0 ? (p_lo + g.stride - 1) / g.stride : 0;
+  int p_hi = (h + g.pad) / g.stride; if (p_hi > g.P - 1) p_hi = g.P - 1;
+  int q_lo = w + g.pad - g.ks + 1; q_lo = q_lo > 0 ? (q_lo + g.stride - 1) / g.stride : 0;
+  int q_hi = (w + g.pad) / g.stride; if (q_hi > g.Q - 1) q_hi = g.Q - 1;
+  for (int p = p_lo; p <= p_hi; ++p) {
+    const int kh = h + g.pad - p * g.stride;
+    for (int q = q_lo; q <= q_hi; ++q) {
+      const int t = kh * g.ks + (w + g.pad - q * g.stride);
+      const long o = ((long)(n * g.P + p) * g.Q + q) * g.C4 + c4;
+      const uchar4 id = reinterpret_cast<const uchar4*>(idx)[o];
+      const f32x4 d = reinterpret_cast<const f32x4*>(dpool)[o];
+      if (id.x == t) acc[0] += d[0];
+      if (id.y == t) acc[1] += d[1];
+      if (id.z == t) acc[2] += d[2];
+      if (id.w == t) acc[3] += d[3];
+    }
+  }
+  const f32x4 z = bnpool_affine(xv, sc, sh);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) if (!(z[e] > 0.f)) acc[e] = 0.f;
+  return acc;
+}
+
+__global__ __launch_bounds__(kBlock) void bnpool_bwd_reduce_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                   const float* __restrict__ x, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, float* __restrict__ part,
+                                                                   int N, int C, PoolGeom g) {
+  __shared__ float red[kBlock][8];
+  const long total = (long)N * g.H * g.W * g.C4;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = (int)(i0 % g.C4);
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  const f32x4 mu = reinterpret_cast<const f32x4*>(mean)[c4], is = reinterpret_cast<const f32x4*>(invstd)[c4];
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / g.C4;
+    const int w = (int)(r % g.W); r /= g.W;
+    const int h = (int)(r % g.H);
+    const int n = (int)(r / g.H);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 gg = bnpool_grad(dpool, idx, xv, sc, sh, n, h, w, c4, g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1[e] += gg[e]; s2[e] += gg[e] * ((xv[e] - mu[e]) * is[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[threadIdx.x][e * 2] = s1[e]; red[threadIdx.x][e * 2 + 1] = s2[e]; }
+  __syncthreads();
+  if ((int)threadIdx.x < g.C4) {                                   // threads t, t + C4, t + 2*C4 ... hold the same channels
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f, b = 0.f;
+      for (int j = threadIdx.x; j < kBlock; j += g.C4) { a += red[j][e * 2]; b += red[j][e * 2 + 1]; }
+      const long c = (long)threadIdx.x * 4 + e;
+      part[((long)blockIdx.x * C + c) * 2 + 0] = a;
+      part[((long)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bnpool_bwd_apply_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+                                                                  const float* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, const float* __restrict__ coef,
+                                                                  float* __restrict__ dx, int N, int C, PoolGeom g) {
+  const long total = (long)N * g.H * g.W * g.C4;
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = (int)(i0 % g.C4);
+  const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4], sh = reinterpret_cast<const f32x4*>(shift)[c4];
+  const f32x4 ca = reinterpret_cast<const f32x4*>(coef)[c4], cb = *reinterpret_cast<const f32x4*>(coef + C + c4 * 4),
+              cc = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4 * 4);
+  for (long i = i0; i < total; i += (long)gridDim.x * blockDim.x) {
+    long r = i / g.C4;
+    const int w = (int)(r % g.W); r /= g.W;
+    const int h = (int)(r % g.H);
+    const int n = (int)(r / g.H);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 gg = bnpool_grad(dpool, idx, xv, sc, sh, n, h, w, c4, g);
+    f32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) out[e] = ca[e] * gg[e] + cb[e] * xv[e] + cc[e];
+    reinterpret_cast<f32x4*>(dx)[i] = out;
+  }
+}
+
+bool bnpool_ok(long C) { return C % 4 == 0 && C >= 4 && C <= 1024 && (kBlock % (C / 4)) == 0; }
+unsigned bnpool_grid(long total) {                                 // <= kMaxRowBlocks blocks: the partials share the BN workspace
+  long g = nnl_cdiv(total, (long)kBlock * 4);
+  if (g > kMaxRowBlocks) g = kMaxRowBlocks;
+  return (unsigned)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int nnl_bn_relu_maxpool_supported(int64_t C) { return bnpool_ok(C) ? 1 : 0; }
+
+extern "C" int nnl_bn_relu_maxpool_fwd(const float* x, const float* gamma, const float* beta, float* y, uint8_t* idx,
+                                       float* save_mean, float* save_invstd, float* save_scale, float* save_shift,
+                                       float* running_mean, float* running_var, int64_t N, int64_t H, int64_t W, int64_t C,
+                                       int64_t P, int64_t Q, int ks, int stride, int pad, float eps, float momentum, int training,
+                                       int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes, void* stream) {
+  const long rows = (long)N * H * W;
+  NNL_CHECK_ARG(N > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && ks > 0 && ks * ks <= 255 && stride > 0 && pad >= 0 && 2 * pad <= ks,
+                "bn_relu_maxpool_fwd: bad geometry");
+  NNL_CHECK_ARG(P == (H + 2 * pad - ks) / stride + 1 && Q == (W + 2 * pad - ks) / stride + 1, "bn_relu_maxpool_fwd: P/Q do not match");
+  NNL_CHECK_ARG(bnpool_ok(C), "bn_relu_maxpool_fwd: C=%ld needs C %% 4 == 0 and C/4 dividing 256", (long)C);
+  NNL_CHECK_ARG(x && y && idx && save_mean && save_invstd && save_scale && save_shift, "bn_relu_maxpool_fwd: null pointer");
+  NNL_CHECK_ARG(training || (running_mean && running_var), "bn_relu_maxpool_fwd: eval mode needs running statistics");
+  NNL_CHECK_ARG(rows * C < (1L << 31) * 4, "bn_relu_maxpool_fwd: tensor too large");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_relu_maxpool_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* scale = save_scale;                       // kept for the backward: its ReLU gate is recomputed from exactly these values
+  float* shift = save_shift;
+  const long CG = C / 4;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (training ? 8.0 : 4.0) + (double)N * P * Q * C * 5.0);
+  if (training) {
+    const Shape sh = make_shape(rows, CG);
+    hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, rows, (int)C, sh.L);
+    NNL_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
+                       save_mean, save_invstd, running_mean, running_var, scale, shift, rows, (int)C, eps, momentum,
+                       (long long*)num_batches_tracked, (float*)nullptr);
+    NNL_CHECK_LAUNCH();
+  } else {
+    NNL_CHECK_HIP(hipMemcpyAsync(save_mean, running_mean, sizeof(float) * C, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(bn_eval_scale_kernel, dim3((unsigned)nnl_cdiv(C, 256)), dim3(256), 0, s, gamma, beta, running_mean,
+                       running_var, scale, shift, save_invstd, (int)C, eps);
+    NNL_CHECK_LAUNCH();
+  }
+  const long total = (long)N * P * Q * CG;
+  hipLaunchKernelGGL(bnpool_fwd_kernel, dim3((unsigned)nnl_cdiv(total, kBlock)), dim3(kBlock), 0, s, x, scale, shift, y, idx, (int)N,
+                     (int)H, (int)W, (int)CG, (int)P, (int)Q, ks, stride, pad);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_bn_relu_maxpool_bwd(const float* dpool, const uint8_t* idx, const float* x, const float* gamma,
+                                       const float* mean, const float* invstd, const float* scale, const float* shift, float* dx,
+                                       float* dgamma, float* dbeta, int64_t N,
+                                       int64_t H, int64_t W, int64_t C, int64_t P, int64_t Q, int ks, int stride, int pad,
+                                       int training, void* workspace, size_t workspace_bytes, void* stream) {
+  const long rows = (long)N * H * W;
+  NNL_CHECK_ARG(N > 0 && H > 0 && W > 0 && P > 0 && Q > 0 && ks > 0 && stride > 0 && pad >= 0, "bn_relu_maxpool_bwd: bad geometry");
+  NNL_CHECK_ARG(bnpool_ok(C), "bn_relu_maxpool_bwd: C=%ld needs C %% 4 == 0 and C/4 dividing 256", (long)C);
+  NNL_CHECK_ARG(dpool && idx && x && mean && invstd && scale && shift && dx, "bn_relu_maxpool_bwd: null pointer");
+  if (workspace == nullptr || workspace_bytes < nnl_bn_workspace_bytes(rows, C))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "bn_relu_maxpool_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  float* coef = part + (long)kMaxRowBlocks * C * 2 + 2 * C;
+  const PoolGeom g{(int)H, (int)W, (int)(C / 4), (int)P, (int)Q, ks, stride, pad};
+  const long total = rows * (C / 4);
+  const unsigned grid = bnpool_grid(total);
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * 12.0 + (double)N * P * Q * C * 10.0);
+  hipLaunchKernelGGL(bnpool_bwd_reduce_kernel, dim3(grid), dim3(kBlock), 0, s, dpool, idx, x, scale, shift, mean, invstd, part, (int)N,
+                     (int)C, g);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, part, (int)grid, gamma, mean, invstd,
+                     dgamma, dbeta, coef, rows, (int)C, training);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bnpool_bwd_apply_kernel, dim3((unsigned)nnl_cdiv(total, kBlock)), dim3(kBlock), 0, s, dpool, idx, x, scale, shift, coef, dx, (int)N, (int)C, g);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
 // ---- SyncBN entry points (split-phase: the host runs the collective between the two halves) -------------------------
 namespace {
 int launch_stats(const float* x, float* part, long rows, long C, hipStream_t s, Shape& sh) {

@@ -565,6 +565,71 @@ class _MaxPool2d(torch.autograd.Function):
         return from_nhwc(dx), None, None, None
 
 
+class _BNReLUMaxPool(torch.autograd.Function):
+    """maxpool(relu(batch_norm(x))) — the ResNet stem tail (reference retinanet.py:372-374) — without materialising the
+    normalised activation: batchnorm.hip nnl_bn_relu_maxpool_{fwd,bwd}.  Saves x (the conv output), the uint8 window index and
+    the per-channel affine."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, nbt, ksize, stride, pad):
+        require_cuda(x, gamma, beta)
+        xn = to_nhwc(x.float())
+        N, H, W, C = xn.shape
+        P, Q = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        dev = x.device
+        y = torch.empty(N, P, Q, C, dtype=torch.float32, device=dev)
+        idx = torch.empty(N, P, Q, C, dtype=torch.uint8, device=dev)
+        stats = torch.empty(4, C, dtype=torch.float32, device=dev)               # mean, invstd, scale, shift
+        wsb = int(lib.nnl_bn_workspace_bytes(N * H * W, C))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+        check(lib.nnl_bn_relu_maxpool_fwd(ptr(xn), ptr(gamma), ptr(beta), ptr(y), ptr(idx), ptr(stats[0]), ptr(stats[1]),
+                                          ptr(stats[2]), ptr(stats[3]), ptr(running_mean), ptr(running_var), N, H, W, C, P, Q,
+                                          ksize, stride, pad, float(eps), float(momentum), int(training), ptr(nbt), ptr(ws), wsb,
+                                          stream()))
+        ctx.save_for_backward(xn, idx, gamma, stats)
+        ctx.cfg = (N, H, W, C, P, Q, ksize, stride, pad, training)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, idx, gamma, stats = ctx.saved_tensors
+        N, H, W, C, P, Q, ksize, stride, pad, training = ctx.cfg
+        dyn = to_nhwc(dy.float())
+        dx = torch.empty_like(xn)
+        dgamma = torch.empty(C, dtype=torch.float32, device=xn.device) if gamma is not None else None
+        dbeta = torch.empty(C, dtype=torch.float32, device=xn.device) if gamma is not None else None
+        wsb = int(lib.nnl_bn_workspace_bytes(N * H * W, C))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=xn.device)
+        check(lib.nnl_bn_relu_maxpool_bwd(ptr(dyn), ptr(idx), ptr(xn), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
+                                          ptr(stats[3]), ptr(dx), ptr(dgamma), ptr(dbeta), N, H, W, C, P, Q, ksize, stride, pad,
+                                          int(training), ptr(ws), wsb, stream()))
+        return (from_nhwc(dx), dgamma, dbeta) + (None,) * 9
+
+
+def conv_bn_relu_maxpool(conv, bn, pool, x):
+    """pool(relu(bn(conv(x)))) for the ResNet stem (conv7x7/2 -> BatchNorm -> ReLU -> MaxPool 3/2/1; reference
+    retinanet.py:304-307,371-374).  BatchNorm, ReLU and the pooling run as one pass over the convolution output whenever the
+    pooling is the plain floor-mode square max-pool and the BatchNorm is a local (non-synchronised) one; otherwise the three
+    stages run one after the other."""
+    k, s, p = pool.kernel_size, pool.stride, pool.padding
+    fuse = (x.is_cuda and isinstance(pool, torch.nn.MaxPool2d) and all(isinstance(v, int) for v in (k, s, p))
+            and pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices and 2 * p <= k and k * k <= 255
+            and not (bn.training and getattr(bn, 'nnl_sync', None) is not None)
+            and (bn.running_mean is not None or bn.training)
+            and not (bn.training and bn.track_running_stats and bn.momentum is None)
+            and bool(lib.nnl_bn_relu_maxpool_supported(bn.num_features)))
+    if not fuse:
+        return pool(conv_bn_act(conv, bn, x, relu=True))
+    y = conv(x)
+    training = bn.training or (bn.running_mean is None)
+    momentum, nbt = 0.0, None
+    if bn.training and bn.track_running_stats:
+        nbt, momentum = bn.num_batches_tracked, bn.momentum
+    rmean = bn.running_mean if (not training or bn.track_running_stats) else None
+    rvar = bn.running_var if (not training or bn.track_running_stats) else None
+    return _BNReLUMaxPool.apply(y, bn.weight, bn.bias, rmean, rvar, training, momentum, bn.eps, nbt, k, s, p)
+
+
 def maxpool2d(x, ksize=3, stride=2, pad=1):
     """nn.MaxPool2d(ksize, stride, pad) (floor mode, no dilation) — the ResNet stem pool (retinanet.py:307,374) — NHWC,
     channel count a multiple of 4; torch's first-maximum tie rule, deterministic gather-style backward (pool.hip)."""
