@@ -416,7 +416,7 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
     if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
     const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
     const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
-    for (long sp = 1; sp <= max_splits && tiles * sp <= 256 * 5; ++sp) {
+    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5); ++sp) {   // unsplit is always a candidate
       const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32) * 32;
       const long rs = nnl_cdiv(Kp, k1);
       if (rs != sp) continue;                                             // same plan as a smaller sp
@@ -451,6 +451,16 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   q.H = H; q.W = W; q.C = C; q.P = P; q.Q = Q; q.R = R; q.S = S; q.stride = stride; q.pad = pad;
   q.Mc = Mc; q.Nc = Nc; q.Kp = (int)Kp;
   q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
+  {
+    // Tile order inside a split: ~128 consecutive tiles run together on one XCD (32 CUs x 4 workgroups) and walk the pixel
+    // range in step; per pixel row they touch (distinct row tiles) x bm columns of dy and (distinct column tiles) x bn of x.
+    // Pick the order with the smaller footprint (the 47343 x 400 decoder gradient: 16.5k floats per pixel row with row tiles
+    // fastest, 4.6k with column tiles fastest).
+    const long T = 128, gm = pl.grid_m, gn = pl.grid_n;
+    const long fp_m = (T < gm ? T : gm) * pl.bm + nnl_cdiv(T, gm) * pl.bn;
+    const long fp_n = nnl_cdiv(T, gn) * pl.bm + (T < gn ? T : gn) * pl.bn;
+    q.n_fast = os_env_int("NNL_WGRAD_NFAST", fp_n < fp_m ? 1 : 0);
+  }
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
   const int bk32 = os_env_int("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
   const char* e_pipe = getenv("NNL_WGRAD_PIPE");                     // A/B hook: 1 = software-pipelined fragment reads

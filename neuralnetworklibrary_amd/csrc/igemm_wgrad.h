@@ -17,6 +17,7 @@ struct IgemmWgradParams {
   int R, S, stride, pad;
   int Mc, Nc, Kp;
   int splits, k_per_split, grid_m, grid_n;
+  int n_fast;          // tile order inside a split: 1 = column tiles fastest (neighbours share the dy columns), 0 = row tiles fastest
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false>
@@ -39,7 +40,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   const int lb = nnl_xcd_remap((int)blockIdx.x, (int)gridDim.x);
   const int split = lb / tiles;
   const int t_id = lb - split * tiles;
-  const int tile_n = t_id / p.grid_m, tile_m = t_id - tile_n * p.grid_m;
+  const int tile_n = p.n_fast ? t_id % p.grid_n : t_id / p.grid_m;
+  const int tile_m = p.n_fast ? t_id / p.grid_n : t_id - tile_n * p.grid_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int k_begin = split * p.k_per_split;
   const int k_end = min(k_begin + p.k_per_split, p.Kp);
