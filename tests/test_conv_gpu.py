@@ -128,3 +128,35 @@ def test_conv2d_balanced_schedule(case, monkeypatch):
         ref.backward(dy[sl].cpu())
         assert_close(y_bal[sl], ref, rtol=1e-4, atol=1e-5 * sy, msg='y vs torch')
         assert_close(dx_bal[sl], xc.grad, rtol=1e-4, atol=1e-5 * sx, msg='dx vs torch')
+
+
+@pytest.mark.parametrize('give_first', [False, True], ids=['producer_runs_first', 'consumer_runs_first'])
+@pytest.mark.parametrize('stride', [1, 2])
+def test_grad_slot_projection_shortcut_hand_over(stride, give_first):
+    """A block input feeds conv1 (3x3, the GradSlot consumer) and the projection shortcut (1x1, the producer that parks its input
+    gradient in the slot).  Whatever order autograd runs the two backward nodes in — there is no dependency between them — the
+    gradient of the input must be the sum of both (the consumer closes the slot; a late producer returns its gradient normally)."""
+    from neuralnetworklibrary_amd import ops
+    g = torch.Generator().manual_seed(21 + stride)
+    N, C, K, H = 2, 32, 48, 12
+    x = torch.randn(N, C, H, H, generator=g)
+    w1 = torch.randn(K, C, 3, 3, generator=g) * 0.1
+    wd = torch.randn(K, C, 1, 1, generator=g) * 0.1
+    xr = x.double().requires_grad_(True)
+    yr = F.conv2d(xr, w1.double(), None, stride, 1) + F.conv2d(xr, wd.double(), None, stride, 0)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    xg = x.to(DEV).requires_grad_(True)
+    w1g = w1.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wdg = wd.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    slot = ops.GradSlot()
+    if give_first:          # created first => its backward node runs LAST: the consumer has closed the slot by then
+        yd = ops.conv2d(xg, wdg, None, stride, 0, give_slot=slot)
+        y1 = ops.conv2d(xg, w1g, None, stride, 1, grad_slot=slot)
+    else:
+        y1 = ops.conv2d(xg, w1g, None, stride, 1, grad_slot=slot)
+        yd = ops.conv2d(xg, wdg, None, stride, 0, give_slot=slot)
+    (y1 + yd).backward(dy.to(DEV))
+    assert slot.tensor is None and slot.closed
+    assert_close(xg.grad, xr.grad.float(), 1e-4, 1e-5 * xr.grad.abs().max().item(), 'dx = dgrad(conv1) + dgrad(shortcut)')
