@@ -473,7 +473,10 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   } else if (pl.bn == 128) {
     hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 16, 2, 2, true>), grid, block, 0, s, q);
   } else {
-    if (bk32 && pl.k_per_split % 32 == 0) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2>), grid, block, 0, s, q);
+    if (bk32 && pl.k_per_split % 32 == 0) {
+      if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2, true>), grid, block, 0, s, q);
+      else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2>), grid, block, 0, s, q);
+    }
     else if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2, true>), grid, block, 0, s, q);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, q);
   }
