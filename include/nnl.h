@@ -128,6 +128,11 @@ int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, const nnl_conv_
 size_t nnl_colsum_workspace_bytes(int64_t rows, int64_t cols);
 int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,
                void* stream);
+/* ReLU backward gate of a conv + bias + ReLU layer (the RetinaNet head convs, retinanet.py:192-199,262-272) fused with its bias
+ * gradient: g[rows,cols] = dy * [y > 0] and, if colsum != NULL, colsum[c] = sum_rows g[:,c] (fixed-order, reproducible) in one
+ * pass over dy and y.  Workspace (only with colsum): nnl_colsum_workspace_bytes(rows, cols). */
+int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ---- K2: BatchNorm fused with the residual add and ReLU that follow it ---------------------------------
  * Replaces nn.BatchNorm2d + `out += residual` + ReLU of BasicBlock/Bottleneck.forward (retinanet.py:47-48,53-57,

@@ -51,6 +51,7 @@ SIGNATURES = {
     'nnl_conv2d_wgrad': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, sz, c_p]),
     'nnl_colsum_workspace_bytes': (sz, [i64, i64]),
     'nnl_colsum': (C.c_int, [c_p, c_p, i64, i64, c_p, sz, c_p]),
+    'nnl_relu_gate_colsum': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, c_p, sz, c_p]),
     'nnl_maxpool2d_fwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_maxpool2d_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_bn_relu_maxpool_supported': (C.c_int, [i64]),

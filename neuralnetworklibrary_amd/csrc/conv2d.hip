@@ -369,6 +369,43 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// ReLU backward gate fused with the bias-gradient column sums: g = dy * [y > 0] is written once and summed per column in the same
+// pass (the conv + bias + ReLU layers of the RetinaNet heads: two ATen kernels and one pass over dy less per layer)
+__global__ __launch_bounds__(256) void relu_gate_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                                float* __restrict__ g, float* __restrict__ part, long rows, int cols,
+                                                                long rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * rows_per_chunk;
+  const long r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+  float acc = 0.f;
+  if (c < cols) {
+    long r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {                       // 8 independent loads in flight per lane
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long o = (r + 4 * u) * cols + c;
+        v[u] = y[o] > 0.f ? dy[o] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) g[(r + 4 * u) * cols + c] = v[u];
+      acc += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (; r < r1; r += 4) {
+      const long o = r * cols + c;
+      const float v = y[o] > 0.f ? dy[o] : 0.f;
+      g[o] = v;
+      acc += v;
+    }
+  }
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols && part != nullptr)
+    part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols,
                                                             int nchunk) {
   // 256 threads = 16 columns x 16 chunk lanes: lane l adds chunks l, l+16, ... (independent loads), then the 16 partial
@@ -796,6 +833,26 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
 extern "C" size_t nnl_colsum_workspace_bytes(int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 0;
   return (size_t)colsum_chunks(rows) * cols * sizeof(float);
+}
+
+extern "C" int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(dy && y && g && rows > 0 && cols > 0 && cols < (1L << 30), "relu_gate_colsum: bad argument");
+  if (colsum != nullptr && (workspace == nullptr || workspace_bytes < nnl_colsum_workspace_bytes(rows, cols)))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "relu_gate_colsum: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 12.0 * rows * cols);
+  const int nchunk = colsum_chunks(rows);
+  const long rpc = nnl_cdiv(nnl_cdiv(rows, nchunk), 4) * 4;
+  hipLaunchKernelGGL(relu_gate_colsum_kernel, dim3((unsigned)nnl_cdiv(cols, 64), nchunk), dim3(256), 0, s, dy, y, g,
+                     colsum ? (float*)workspace : nullptr, (long)rows, (int)cols, rpc);
+  NNL_CHECK_LAUNCH();
+  if (colsum != nullptr) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nnl_cdiv(cols, 16)), dim3(256), 0, s, (const float*)workspace, colsum,
+                       (int)cols, nchunk);
+    NNL_CHECK_LAUNCH();
+  }
+  return NNL_OK;
 }
 
 extern "C" int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,

@@ -248,8 +248,19 @@ class _Conv2d(torch.autograd.Function):
         xn, wn, y = ctx.saved_tensors
         g = ctx.g
         dyn = to_nhwc(dy.float())
-        if ctx.relu:
+        db_gated = None
+        if ctx.relu and os.environ.get('NNL_RELU_GATE', '1') == '0':
             dyn = dyn * (y > 0)
+        elif ctx.relu:
+            # ReLU gate (+ the bias gradient of the gated dy) in one pass
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
+            rows = g.N * g.P * g.Q
+            gated = torch.empty_like(dyn)
+            cb = int(lib.nnl_colsum_workspace_bytes(rows, g.K)) if want_db else 0
+            cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device) if want_db else None
+            db_gated = torch.empty(g.K, dtype=torch.float32, device=dyn.device) if want_db else None
+            check(lib.nnl_relu_gate_colsum(ptr(dyn), ptr(y), ptr(gated), ptr(db_gated), rows, g.K, ptr(cws), cb, stream()))
+            dyn = gated
         K = g.K
         if K % 4 != 0:                      # e.g. RetinaNet 36/180-channel output convs: pad dy's channels
             dyn = _pad_c4(dyn)
@@ -292,7 +303,9 @@ class _Conv2d(torch.autograd.Function):
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dyn.device)
             check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
             dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if db_gated is not None:
+            db = db_gated
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             db_full = torch.empty(g.K, dtype=torch.float32, device=dyn.device)
             cb = int(lib.nnl_colsum_workspace_bytes(g.N * g.P * g.Q, g.K))
             cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device)
