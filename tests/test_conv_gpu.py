@@ -160,3 +160,16 @@ def test_grad_slot_projection_shortcut_hand_over(stride, give_first):
     (y1 + yd).backward(dy.to(DEV))
     assert slot.tensor is None and slot.closed
     assert_close(xg.grad, xr.grad.float(), 1e-4, 1e-5 * xr.grad.abs().max().item(), 'dx = dgrad(conv1) + dgrad(shortcut)')
+
+
+DMA_CASES = [c for c in CASES if c[1] % 32 == 0 and c[4] % 4 == 0][:6] + [(16, 64, 56, 56, 64, 3, 1, 1, False, False),
+                                                                            (16, 256, 14, 14, 256, 3, 1, 1, True, True)]
+
+
+@pytest.mark.parametrize('case', DMA_CASES, ids=[str(c) for c in DMA_CASES])
+def test_conv2d_lds_dma_staging_variant(case, monkeypatch):
+    """The LDS-DMA staging variant of the 64x64 kernels (NNL_IGEMM_DMA, off by default: DESIGN.md switches table) computes the
+    same convolution: forward / dgrad through `buffer_load ... lds` into the swizzled unpadded image, three (BK 16) or two
+    (BK 32) buffers, on plain and balanced grids."""
+    monkeypatch.setenv('NNL_IGEMM_DMA', '3')
+    test_conv2d_fwd_bwd(case)
