@@ -116,20 +116,24 @@ __global__ __launch_bounds__(kBlock) void bn_stats_kernel(const float* __restric
 
 // Sum the per-block partials of channel c: 64 lanes each add a strided subset (fixed order), then a fixed-order
 // tree over the lanes in LDS.  Block = 256 threads = 4 channels x 64 lanes.  Returns the sums to lane 0.
+template <int LANES = kFinLanes>
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nparts, int C, int c, bool cok,
-                                                float (*red)[kFinLanes][2], float& s1, float& s2) {
-  const int lane = threadIdx.x & (kFinLanes - 1), ch = threadIdx.x / kFinLanes;
+                                                float (*red)[LANES][2], float& s1, float& s2) {
+  const int lane = threadIdx.x & (LANES - 1), ch = threadIdx.x / LANES;
   float a = 0.f, b = 0.f;
   if (cok) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const f32x2* pp = reinterpret_cast<const f32x2*>(part) + c;          // (S1, S2) pairs, stride C
     int p = lane;
-    for (; p + 3 * kFinLanes < nparts; p += 4 * kFinLanes) {            // 4 independent 8-B loads in flight (the partials
-      const f32x2 v0 = pp[(long)p * C], v1 = pp[(long)(p + kFinLanes) * C];      // were written by other XCDs: each load
-      const f32x2 v2 = pp[(long)(p + 2 * kFinLanes) * C], v3 = pp[(long)(p + 3 * kFinLanes) * C];   // is a ~1 us miss)
-      a += v0[0]; b += v0[1]; a += v1[0]; b += v1[1]; a += v2[0]; b += v2[1]; a += v3[0]; b += v3[1];
+    constexpr int U = 8;                                                // independent 8-B loads in flight per lane: the partials
+    for (; p + (U - 1) * LANES < nparts; p += U * LANES) {      // were written by other XCDs, each load is a ~1 us miss
+      f32x2 v[U];                                                       // (3136 conv-epilogue partials per channel on the 56x56
+#pragma unroll                                                          // stage: 14 -> 7 us per finalize); added in index order
+      for (int u = 0; u < U; ++u) v[u] = pp[(long)(p + u * LANES) * C];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { a += v[u][0]; b += v[u][1]; }
     }
-    for (; p < nparts; p += kFinLanes) {
+    for (; p < nparts; p += LANES) {
       const f32x2 v = pp[(long)p * C];
       a += v[0]; b += v[1];
     }
@@ -137,7 +141,7 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
   red[ch][lane][0] = a;
   red[ch][lane][1] = b;
   __syncthreads();
-  for (int w = kFinLanes / 2; w > 0; w >>= 1) {
+  for (int w = LANES / 2; w > 0; w >>= 1) {
     if (lane < w) {
       red[ch][lane][0] += red[ch][lane + w][0];
       red[ch][lane][1] += red[ch][lane + w][1];
@@ -171,18 +175,19 @@ __device__ __forceinline__ void finish_stats(int c, int C, float m, float var, f
 }
 
 // ---- finalize: mean / invstd, running statistics, per-channel scale & shift ----------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,
+template <int LANES>                  // partial-sum lanes per channel: 64 (4 channels per block) or 256 (one channel per block: the
+__global__ void bn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ part, int nparts,   // conv-epilogue partials)
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ scale, float* __restrict__ shift, long rows, int C, float eps,
                                    float momentum, long long* __restrict__ num_batches_tracked,
                                    float* __restrict__ pivot_out) {
-  __shared__ float red[4][kFinLanes][2];
-  const int c = blockIdx.x * 4 + threadIdx.x / kFinLanes;
+  __shared__ float red[256 / LANES][LANES][2];
+  const int c = blockIdx.x * (256 / LANES) + threadIdx.x / LANES;
   float s1, s2;
-  reduce_partials(part, nparts, C, c, c < C, red, s1, s2);
-  if (c >= C || (threadIdx.x & (kFinLanes - 1)) != 0) return;
+  reduce_partials<LANES>(part, nparts, C, c, c < C, red, s1, s2);
+  if (c >= C || (threadIdx.x & (LANES - 1)) != 0) return;
   if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;     // nn.BatchNorm's counter, without its own launch
   const float n = (float)rows;
   const float m = x[c] + s1 / n;
@@ -537,9 +542,14 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * (training ? 12.0 : 8.0) + (residual ? 4.0 * rows * C : 0.0));
   if (training && ext_partials != nullptr && ext_rows > 0 && ext_pivot != nullptr) {
     // the producing convolution already reduced every 64-row tile: only the finalize (pivot = the conv's pivot)
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, ext_pivot, ext_partials, (int)ext_rows,
-                       gamma, beta, save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps,
-                       momentum, (long long*)num_batches_tracked, pivot_out);
+    if (ext_rows >= 1024)      // one partial per 64-row tile of the convolution: thousands on the early stages
+      hipLaunchKernelGGL(bn_finalize_kernel<256>, dim3((unsigned)C), dim3(256), 0, s, ext_pivot, ext_partials, (int)ext_rows, gamma, beta,
+                         save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps, momentum,
+                         (long long*)num_batches_tracked, pivot_out);
+    else
+      hipLaunchKernelGGL(bn_finalize_kernel<kFinLanes>, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, ext_pivot, ext_partials,
+                         (int)ext_rows, gamma, beta, save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows,
+                         (int)C, eps, momentum, (long long*)num_batches_tracked, pivot_out);
     NNL_CHECK_LAUNCH();
   } else if (training) {
     const Shape sh = make_shape(rows, CG);
@@ -548,7 +558,7 @@ extern "C" int nnl_bn_fwd(const float* x, const float* gamma, const float* beta,
     else
       hipLaunchKernelGGL(bn_stats_kernel<1>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, (long)rows, (int)C, sh.L);
     NNL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel<kFinLanes>, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
                        save_mean, save_invstd, running_mean, running_var, scale, shift, (long)rows, (int)C, eps, momentum,
                        (long long*)num_batches_tracked, pivot_out);
     NNL_CHECK_LAUNCH();
@@ -686,12 +696,14 @@ __device__ __forceinline__ f32x4 bnpool_grad(const float* __restrict__ dpool, co
   return acc;
 }
 
-__global__ __launch_bounds__(kBlock) void bnpool_bwd_reduce_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
+constexpr int kPoolRedBlock = 1024;          // 16 waves per block: the gathers are latency-bound, so 2 blocks x 16 waves fill a CU
+
+__global__ __launch_bounds__(kPoolRedBlock) void bnpool_bwd_reduce_kernel(const float* __restrict__ dpool, const uint8_t* __restrict__ idx,
                                                                    const float* __restrict__ x, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, float* __restrict__ part,
                                                                    int N, int C, PoolGeom g) {
-  __shared__ float red[kBlock][8];
+  __shared__ float red[kPoolRedBlock][8];
   const long total = (long)N * g.H * g.W * g.C4;
   const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int c4 = (int)(i0 % g.C4);
@@ -715,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void bnpool_bwd_reduce_kernel(const float* 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float a = 0.f, b = 0.f;
-      for (int j = threadIdx.x; j < kBlock; j += g.C4) { a += red[j][e * 2]; b += red[j][e * 2 + 1]; }
+      for (int j = threadIdx.x; j < kPoolRedBlock; j += g.C4) { a += red[j][e * 2]; b += red[j][e * 2 + 1]; }
       const long c = (long)threadIdx.x * 4 + e;
       part[((long)blockIdx.x * C + c) * 2 + 0] = a;
       part[((long)blockIdx.x * C + c) * 2 + 1] = b;
@@ -749,7 +761,7 @@ __global__ __launch_bounds__(kBlock) void bnpool_bwd_apply_kernel(const float* _
 
 bool bnpool_ok(long C) { return C % 4 == 0 && C >= 4 && C <= 1024 && (kBlock % (C / 4)) == 0; }
 unsigned bnpool_grid(long total) {                                 // <= kMaxRowBlocks blocks: the partials share the BN workspace
-  long g = nnl_cdiv(total, (long)kBlock * 4);
+  long g = nnl_cdiv(total, (long)kPoolRedBlock * 4);
   if (g > kMaxRowBlocks) g = kMaxRowBlocks;
   return (unsigned)(g < 1 ? 1 : g);
 }
@@ -783,7 +795,7 @@ extern "C" int nnl_bn_relu_maxpool_fwd(const float* x, const float* gamma, const
     const Shape sh = make_shape(rows, CG);
     hipLaunchKernelGGL(bn_stats_kernel<4>, dim3(sh.gx, sh.gy), dim3(kBlock), 0, s, x, part, rows, (int)C, sh.L);
     NNL_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel<kFinLanes>, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, x, part, sh.gx, gamma, beta,
                        save_mean, save_invstd, running_mean, running_var, scale, shift, rows, (int)C, eps, momentum,
                        (long long*)num_batches_tracked, (float*)nullptr);
     NNL_CHECK_LAUNCH();
@@ -818,7 +830,7 @@ extern "C" int nnl_bn_relu_maxpool_bwd(const float* dpool, const uint8_t* idx, c
   const long total = rows * (C / 4);
   const unsigned grid = bnpool_grid(total);
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)rows * C * 12.0 + (double)N * P * Q * C * 10.0);
-  hipLaunchKernelGGL(bnpool_bwd_reduce_kernel, dim3(grid), dim3(kBlock), 0, s, dpool, idx, x, scale, shift, mean, invstd, part, (int)N,
+  hipLaunchKernelGGL(bnpool_bwd_reduce_kernel, dim3(grid), dim3(kPoolRedBlock), 0, s, dpool, idx, x, scale, shift, mean, invstd, part, (int)N,
                      (int)C, g);
   NNL_CHECK_LAUNCH();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)nnl_cdiv(C, 4)), dim3(256), 0, s, part, (int)grid, gamma, mean, invstd,
