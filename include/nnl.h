@@ -174,9 +174,12 @@ int nnl_bn_relu_maxpool_fwd(const float* x, const float* gamma, const float* bet
                             float momentum, int training, int64_t* num_batches_tracked, void* workspace, size_t workspace_bytes,
                             void* stream);
 /* dx [N,H,W,C], dgamma, dbeta from the pooled gradient dpool [N,P,Q,C]: every input pixel gathers dpool over the windows whose
- * arg-max it is (no atomics: reproducible), gated by the recomputed ReLU, then the two BatchNorm backward passes. */
-int nnl_bn_relu_maxpool_bwd(const float* dpool, const uint8_t* idx, const float* x, const float* gamma, const float* mean,
-                            const float* invstd, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+ * arg-max it is (no atomics: reproducible), gated by the recomputed ReLU, then the two BatchNorm backward passes.  y (optional: the
+ * forward's pooled output) lets the reduction pass run over the pooled outputs alone (xhat at an arg-max = (y - beta) / gamma):
+ * it then reads neither x nor the windows. */
+int nnl_bn_relu_maxpool_bwd(const float* dpool, const float* y, const uint8_t* idx, const float* x, const float* gamma,
+                            const float* beta, const float* mean, const float* invstd, const float* scale, const float* shift,
+                            float* dx, float* dgamma, float* dbeta,
                             int64_t N, int64_t H, int64_t W, int64_t C, int64_t P, int64_t Q, int ks, int stride, int pad,
                             int training, void* workspace, size_t workspace_bytes, void* stream);
 

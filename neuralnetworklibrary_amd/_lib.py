@@ -57,7 +57,7 @@ SIGNATURES = {
     'nnl_bn_relu_maxpool_supported': (C.c_int, [i64]),
     'nnl_bn_relu_maxpool_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, i64, i64,
                                           C.c_int, C.c_int, C.c_int, f32, f32, C.c_int, c_p, c_p, sz, c_p]),
-    'nnl_bn_relu_maxpool_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, i64, i64,
+    'nnl_bn_relu_maxpool_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, i64, i64,
                                           C.c_int, C.c_int, C.c_int, C.c_int, c_p, sz, c_p]),
     'nnl_concat_pool_fwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, c_p]),
     'nnl_concat_pool_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, c_p]),

@@ -599,13 +599,13 @@ class _BNReLUMaxPool(torch.autograd.Function):
                                           ptr(stats[2]), ptr(stats[3]), ptr(running_mean), ptr(running_var), N, H, W, C, P, Q,
                                           ksize, stride, pad, float(eps), float(momentum), int(training), ptr(nbt), ptr(ws), wsb,
                                           stream()))
-        ctx.save_for_backward(xn, idx, gamma, stats)
+        ctx.save_for_backward(xn, idx, gamma, beta, stats, y)
         ctx.cfg = (N, H, W, C, P, Q, ksize, stride, pad, training)
         return from_nhwc(y)
 
     @staticmethod
     def backward(ctx, dy):
-        xn, idx, gamma, stats = ctx.saved_tensors
+        xn, idx, gamma, beta, stats, y = ctx.saved_tensors
         N, H, W, C, P, Q, ksize, stride, pad, training = ctx.cfg
         dyn = to_nhwc(dy.float())
         dx = torch.empty_like(xn)
@@ -613,8 +613,8 @@ class _BNReLUMaxPool(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=xn.device) if gamma is not None else None
         wsb = int(lib.nnl_bn_workspace_bytes(N * H * W, C))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=xn.device)
-        check(lib.nnl_bn_relu_maxpool_bwd(ptr(dyn), ptr(idx), ptr(xn), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]),
-                                          ptr(stats[3]), ptr(dx), ptr(dgamma), ptr(dbeta), N, H, W, C, P, Q, ksize, stride, pad,
+        check(lib.nnl_bn_relu_maxpool_bwd(ptr(dyn), ptr(y), ptr(idx), ptr(xn), ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]),
+                                          ptr(stats[2]), ptr(stats[3]), ptr(dx), ptr(dgamma), ptr(dbeta), N, H, W, C, P, Q, ksize, stride, pad,
                                           int(training), ptr(ws), wsb, stream()))
         return (from_nhwc(dx), dgamma, dbeta) + (None,) * 9
 

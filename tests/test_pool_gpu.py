@@ -92,6 +92,7 @@ def test_bn_relu_maxpool_fused_matches_the_three_stages(training, shape):
     with torch.no_grad():
         for bn in (bn_a, bn_b, bn_r):
             bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.4, 0.4, C))
+            bn.weight[:3] = torch.tensor([1e-3, 0.0, -0.7])         # tiny / zero / negative gamma: the backward's slow and sign paths
             bn.running_mean.copy_(torch.linspace(-0.2, 0.5, C)); bn.running_var.copy_(torch.linspace(0.8, 2.5, C))
     bn_a, bn_b = bn_a.to(DEV).train(training), bn_b.to(DEV).train(training)
     bn_r.train(training)
