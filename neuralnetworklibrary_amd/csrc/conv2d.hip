@@ -106,7 +106,7 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   if ((e && atoi(e) == 0) || Nc % 4 != 0) return best;
   const long gm = nnl_cdiv(M, bm), gn = nnl_cdiv(Nc, 64), T = gm * gn;
   const char* e_bk = getenv("NNL_IGEMM_BK32");
-  const int bk = (bm == 64 && (e_bk ? atoi(e_bk) : (T < 1200)) && C % 32 == 0) ? 32 : 16;
+  const int bk = (bm == 64 && (e_bk ? atoi(e_bk) : (T < 1200 || C >= 256)) && C % 32 == 0) ? 32 : 16;
   const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
   const double c_it = (bk == 32 ? 0.60 : 0.30) * (bm / 64);            // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
   const double occ = bm == 128 ? 5 : (bk == 32 ? 4 : 6);               // resident workgroups per CU (LDS- / VGPR-limited)
@@ -276,7 +276,7 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
       const char* e_bk = getenv("NNL_IGEMM_BK32");
       const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64) * (p.ncls > 1 ? p.ncls : 1);
-      const int bk32 = e_bk ? atoi(e_bk) : (blocks64 < 1200);
+      const int bk32 = e_bk ? atoi(e_bk) : (blocks64 < 1200 || p.C >= 256);   // long k loops (C >= 256) gain from BK=32 on large grids too (RetinaNet heads)
       if (bk32 && p.C % 32 == 0) return launch_taps<64, 64, 32>(p, s);
       return launch_taps<64, 64>(p, s);
     }
