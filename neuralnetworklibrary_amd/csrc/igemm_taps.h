@@ -7,14 +7,15 @@
 // of an [N][OH][OW][Nc] tensor.  This one kernel covers
 //   * conv forward           : taps = all (r,s), (dh,dw) = (r,s), in_stride = stride, ih0 = -pad;
 //   * dgrad, stride 1        : taps = all (r,s), (dh,dw) = (pad-r, pad-s) over dy, B = W^T [C][R][S][K];
-//   * dgrad, stride 2        : one launch per output-parity class (ph,pw) with only the taps whose parity matches
-//                              (no zero taps fed to the MFMA), out_stride = 2, (oh0,ow0) = (ph,pw);
+//   * dgrad, stride 2        : per output-parity class (ph,pw) only the taps whose parity matches (no zero taps fed to the
+//                              MFMA), out_stride = 2, (oh0,ow0) = (ph,pw); the four classes share ONE launch (ncls) when H, W even;
 //   * Linear / plain NT GEMM : one tap, H = W = P = Q = 1.
 // Differences from the first-generation kernel (igemm_kernels.h): operands are fetched with BUFFER loads (SRD +
 // 32-bit per-lane offset + scalar per-k-step offset; out-of-range lanes return 0, so padding / ragged tiles need no
-// branches), tap validity is a per-row bit mask computed once, the k loop carries only scalar state, and the loop body
-// is a single basic block (the last iteration re-fetches the last tile instead of branching), which lets the compiler
-// interleave the ~20 address instructions with the 32 MFMAs of a k-step.
+// branches), tap validity is a per-row bit mask computed once, the k loop carries only scalar state, and everything that
+// depends on the tap (row offsets with the validity folded in, the two table entries) is refreshed at tap boundaries only:
+// the steady-state iteration is buffer loads + ds_reads + MFMAs + ds_writes + one barrier (the last iteration re-fetches the
+// last tile instead of changing shape).
 #pragma once
 #include "igemm.h"
 
