@@ -1,6 +1,8 @@
 """GPU parity of the implicit-GEMM conv2d (fwd / dgrad / wgrad, through the C ABI) against torch CPU fp32
 (the reference's conv is torch's: retinanet.py:26-28 etc.).  Tolerance: 1e-3 relative (north_star) — the fp32 MFMA
 is an exact fmaf chain, observed error is ~1e-6."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -97,7 +99,8 @@ def test_conv2d_balanced_schedule(case, monkeypatch):
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
     b = torch.randn(K, generator=g) if has_bias else None
     geom = ops._geom(N, H, H, C, K, R, R, stride, pad)
-    assert lib.nnl_conv2d_fwd_workspace_bytes(geom) > 0, 'case does not exercise the balanced schedule'
+    if os.environ.get('NNL_IGEMM_BALANCE', '1') != '0':          # (the A/B switch turns the schedule off: plain-grid parity only)
+        assert lib.nnl_conv2d_fwd_workspace_bytes(geom) > 0, 'case does not exercise the balanced schedule'
 
     def run():
         xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
