@@ -151,13 +151,8 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
 }
 
 BalPlan plan_balance(long M, int Nc, int C, int ntaps) {
-  BalPlan p64 = plan_balance_tile(M, Nc, C, ntaps, 64);
-  const char* e = getenv("NNL_IGEMM_BM128");                           // experiment: also consider the 128x64 tile
-  if (e && atoi(e) >= 1 && M >= 4096) {
-    BalPlan p128 = plan_balance_tile(M, Nc, C, ntaps, 128);
-    if (p128.on && (p128.t_us < p64.t_us || atoi(e) == 2)) return p128;
-  }
-  return p64;
+  // (a 128x64 tile under this schedule was measured 10-12 % slower on the 56x56 and 14x14 stages and removed: profiles/README.md)
+  return plan_balance_tile(M, Nc, C, ntaps, 64);
 }
 
 size_t balance_workspace_bytes(long M, int Nc, int C, int ntaps) {
@@ -189,9 +184,7 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counte
   p.tail_out = ws + pl.main_floats; p.tail_slab_stride = (long)(p.M - pl.tail_row0) * p.Nc;
   p.tile_counters = (pl.bm == 64) ? counters : nullptr;      // in-kernel fix-up of the split tiles (64x64 tile only)
   const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
-  if (pl.bm == 128)
-    hipLaunchKernelGGL((igemm_taps_kernel<128, 64, 16, 2, 2>), dim3(grid), dim3(256), 0, s, p);
-  else if (pl.bk == 32 && taps_dma(32, p))
+  if (pl.bk == 32 && taps_dma(32, p))
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk != 32 && taps_dma(16, p))
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
