@@ -268,6 +268,14 @@ class _Conv2d(torch.autograd.Function):
             g = _geom(g.N, g.H, g.W, g.C, dyn.shape[-1], g.R, g.S, g.stride, g.pad)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
+            g_w, dyn_w, wn_w = g, dyn, wn                   # (the weight gradient keeps the unpadded operands)
+            if g.K % 16 != 0 and g.K >= 32 and os.environ.get('NNL_DGRAD_PAD16', '1') != '0':
+                # dgrad reduces over K: the tap-table kernel needs K % 16 == 0 (RetinaNet's 36- / 180-channel output convs would
+                # fall back to the first-generation kernel, ~2.5x slower); zero channels cost one copy of dy
+                padk = 16 - g.K % 16
+                dyn = torch.nn.functional.pad(dyn, (0, padk))
+                wn = torch.nn.functional.pad(wn, (0, 0, 0, 0, 0, 0, 0, padk))
+                g = _geom(g.N, g.H, g.W, g.C, g.K + padk, g.R, g.S, g.stride, g.pad)
             wt = _WT_ACTIVE.get(wn.data_ptr()) if g.K == K else None
             if wt is None or tuple(wt.shape) != (g.C, g.R, g.S, g.K):
                 wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
@@ -290,6 +298,7 @@ class _Conv2d(torch.autograd.Function):
                 give.tensor = dxn                           # the block's first conv adds it inside its dgrad kernel
             else:
                 dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
+            g, dyn, wn = g_w, dyn_w, wn_w
         elif ctx.slot is not None:
             ctx.slot.tensor, ctx.slot.closed = None, True
         if ctx.needs_input_grad[1]:
