@@ -71,6 +71,31 @@ def _batch_size(y_batch):
     return len(y_batch) if type(y_batch) != list else len(y_batch[0])
 
 
+def _raise_if_index_error():
+    """The gather kernels (embeddings, tabular front end, softmax-CE targets) skip an out-of-range index and raise a device
+    flag instead of faulting; the reference's nn.Embedding / CrossEntropyLoss would have raised.  Read the flag once per
+    epoch / evaluate / predict (one D2H copy) and raise IndexError on EVERY rank of a data-parallel job."""
+    if default_device().type != 'cuda':
+        return
+    from .. import ops
+    d = _dist()
+    if d is None:
+        ops.raise_if_index_error()
+        return
+    flag = ops.index_error_flag(default_device())
+    total = flag.clone()
+    d.all_reduce(total, op=d.ReduceOp.MAX)
+    if int(total.item()) != 0:
+        flag.zero_()
+        raise IndexError("index out of range in self")
+
+
+def _own_rows(dl, y_batch):
+    "rows of this shard that count: a sharding loader's ghost shard (dist.shard_bounds) counts 0"
+    info = getattr(dl, 'dp_info', None)
+    return info[0] if info is not None else _batch_size(y_batch)
+
+
 def plot_confusion_matrix(cm, classes, normalize=False, title='Confusion matrix', cmap=None):
     "Plot a confusion matrix (General/Learner.py:32-60; UI helper)."
     import itertools
@@ -161,11 +186,15 @@ class Learner(object):
         self.grad_sync = None
         self._graph_warmup, self._graphs = None, {}
         self._loss_host, self._loss_event = None, None
+        self._dp_weight, self._dp_equal_shards = 1.0, False
 
     # ---- data parallelism (new) -----------------------------------------------------
-    def distribute(self, bucket_mb=25.0, sync_bn=False):
-        """Make this learner one rank of a synchronous data-parallel job (one process per GPU)."""
+    def distribute(self, bucket_mb=25.0, sync_bn=False, equal_shards=False):
+        """Make this learner one rank of a synchronous data-parallel job (one process per GPU).
+        equal_shards=True is a promise that every minibatch gives every rank the same number of rows (drop_last loaders,
+        synthetic benchmarks): it skips the per-step batch-size agreement described at `_dp_batch_sizes`."""
         from .. import dist as nnl_dist
+        self._dp_equal_shards = bool(equal_shards)
         self.grad_sync = nnl_dist.GradSync(self.model, bucket_mb=bucket_mb)
         self.optimizer.attach_grad_sync(self.grad_sync)
         if sync_bn:
@@ -190,13 +219,25 @@ class Learner(object):
             self.grad_sync.rebuild()
             self.optimizer.attach_grad_sync(self.grad_sync)
 
-    def _global_bs(self, bs):
+    def _dp_batch_sizes(self, bs):
+        """(rows of this rank's shard that count, rows of the GLOBAL minibatch, rows of a full global minibatch, world) under data
+        parallelism.  The decision is RANK-UNIFORM — every rank takes the same branch for the same minibatch, whatever its own
+        shard looks like (a ragged global batch of 7 over 2 ranks is 4 + 3: only one of them is short):
+          * the sharding loaders (dist.ShardedBatches, device_data.DeviceBatches) publish `dp_info` = (local, global) with each
+            shard, no communication needed;
+          * `distribute(equal_shards=True)`: global = local x world by promise;
+          * anything else: one small all-reduce of the local row count per step (a host sync, but always correct)."""
         d = _dist()
-        if d is None:
-            return bs, self.data.bs
+        world = d.get_world_size() if d else 1
+        full = self.data.bs * world
+        info = getattr(self.data.train_dl, 'dp_info', None)
+        if info is not None:
+            return info[0], info[1], full, world
+        if d is None or getattr(self, '_dp_equal_shards', False):
+            return bs, bs * world, full, world
         t = torch.tensor([float(bs)], device=default_device())
         d.all_reduce(t)
-        return int(t.item()), self.data.bs * d.get_world_size()
+        return bs, int(t.item()), full, world
 
     # ---- (1) save / load (General/Learner.py:119-153) ---------------------------------------------
     def save(self, filename, save_optimizer=False):
@@ -348,6 +389,7 @@ class Learner(object):
                     B, Cl, Sc = B[0], Cl[0], Sc[0]          # bs = 1 for 'val' / 'test' bbox loaders
                     ds = self.data.val_ds if which == 'val' else self.data.test_ds
                     out.append([list_mult(B, 1 / ds.images[j]['scale']), Cl, Sc])
+        _raise_if_index_error()
         if self.target_type == 'cont':
             return ARR(torch.cat(out))
         if self.target_type in ['cat', 'single_label', 'text_classify']:
@@ -382,11 +424,12 @@ class Learner(object):
             acc = torch.zeros((), dtype=torch.float64, device=dev)
             with torch.no_grad():
                 for x_batch, y_batch in self.data.train_dl:
-                    bs = _batch_size(y_batch)
+                    bs = _own_rows(self.data.train_dl, y_batch)
                     x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
                     acc += bs * as_f64(self.loss_func(self.predict1minibatch(x_batch), y_batch))
                     n_seen += bs
             total_loss, n_seen = self._allreduce_sums([acc.item(), n_seen])
+            _raise_if_index_error()
             return total_loss / n_seen
 
         if dataset_type == 'val':
@@ -394,7 +437,7 @@ class Learner(object):
             acc = torch.zeros(2 + len(metrics), dtype=torch.float64, device=dev)      # [loss, num_correct, metrics...]
             with torch.no_grad():
                 for x_batch, y_batch in self.data.val_dl:
-                    bs = _batch_size(y_batch)
+                    bs = _own_rows(self.data.val_dl, y_batch)
                     x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
                     y_pred = self.predict1minibatch(x_batch)
                     acc[0] += bs * as_f64(self.loss_func(y_pred, y_batch))
@@ -405,7 +448,9 @@ class Learner(object):
                         if isinstance(m, str) and m in end_metrics:
                             continue
                         acc[2 + i] += bs * as_f64(m(y_pred, y_batch))
-                    if self.target_type in ['cat', 'single_label']:
+                    if bs == 0:
+                        pass                                  # ghost shard of a data-parallel loader: counts nothing
+                    elif self.target_type in ['cat', 'single_label']:
                         acc[1] += (y_pred.max(dim=1)[1] == y_batch).sum()
                     elif self.target_type == 'multi_label':
                         acc[1] += (y_pred.sigmoid().round() == y_batch).sum()
@@ -415,6 +460,7 @@ class Learner(object):
                     if isinstance(m, str) and m in end_metrics:
                         acc[2 + i] = n_seen * as_f64(end_metrics[m]()(YPRED, Y))
             host = acc.tolist()                                                      # the only device->host sync
+            _raise_if_index_error()
             sums = self._allreduce_sums([host[0], n_seen, host[1]] + host[2:])
             total_loss, n_seen, num_correct = sums[0], sums[1], sums[2]
             metric_values = np.array(sums[3:]) / n_seen
@@ -432,8 +478,11 @@ class Learner(object):
         """One optimizer update on one minibatch; returns the minibatch loss as a float
         (General/Learner.py:490-516)."""
         bs = _batch_size(y_batch)
+        self._dp_weight = 1.0
         if self.grad_sync is not None:
-            bs, full_bs = self._global_bs(bs) if bs < self.data.bs else (bs, bs)
+            local, bs, full_bs, world = self._dp_batch_sizes(bs)
+            # this rank's share of the global minibatch relative to an equal split (SURVEY.md §8e: local_bs / global_bs weighting)
+            self._dp_weight = local * world / max(bs, 1)
         else:
             full_bs = self.data.bs
         if bs < full_bs:
@@ -455,7 +504,7 @@ class Learner(object):
         opt = self.optimizer
         opt.opt.zero_grad()
         if self.grad_sync is not None:
-            self.grad_sync.begin()
+            self.grad_sync.begin(self._dp_weight)
         y_pred = self.predict1minibatch(x_batch)
         loss = self.loss_func(y_pred, y_batch)
         early = loss.is_cuda and loss.numel() == 1 and not torch.cuda.is_current_stream_capturing()
@@ -557,6 +606,7 @@ class Learner(object):
                                              and (j % print_batch) == 0):
                     self._print_batch(j, debiased, loss, metrics, x_batch, y_batch, time.time() - tb)
 
+            _raise_if_index_error()                       # bad ids met by this epoch's gathers (checked once, not per step)
             train_loss = debiased if self.use_moving_avg else self.evaluate('train')
 
             res = self.evaluate('val', metrics)
@@ -727,6 +777,7 @@ class Learner(object):
                 if (break_fac and debiased > break_fac * initial_loss) or i == N - 1:
                     break
 
+        _raise_if_index_error()
         if plot and _rank() == 0:
             import matplotlib.pyplot as plt
             fig = plt.figure(figsize=(12, 6))

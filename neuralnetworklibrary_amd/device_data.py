@@ -13,6 +13,8 @@ schedules agree on every rank and the union of the ranks' minibatches is exactly
 """
 import torch
 
+from .dist import shard_bounds
+
 __all__ = ['DeviceBatches']
 
 
@@ -37,6 +39,7 @@ class DeviceBatches:
         self.bs, self.shuffle, self.seed, self.rank, self.world = int(bs), shuffle, int(seed), int(rank), int(world)
         self.epoch = 0
         self._gen = None
+        self.dp_info = None          # (rows of the last yielded shard that count, rows of its GLOBAL minibatch): Learner reads it
 
     def __len__(self):
         g = self.bs * self.world
@@ -57,8 +60,9 @@ class DeviceBatches:
         for b in range(len(self)):
             lo = b * g
             hi = min(lo + g, self.n)
-            per = (hi - lo + self.world - 1) // self.world     # contiguous per-rank slice, as dist.ShardedBatches cuts it
-            a, z = lo + self.rank * per, min(lo + (self.rank + 1) * per, hi)
+            a, z, ghost = shard_bounds(hi - lo, self.rank, self.world)   # balanced contiguous cut, as dist.ShardedBatches
+            a, z = lo + a, lo + z
+            self.dp_info = (0 if ghost else z - a, hi - lo)
             if perm is None:
                 take = lambda t: t[a:z]
             else:

@@ -8,8 +8,9 @@ from a post-accumulate-grad hook as soon as its last gradient is produced, i.e. 
 of backward is still running on the compute stream (RCCL runs on its own stream).  `finish()` (called by
 Optimizer.step) waits for the collectives, and `param.grad` becomes a view of the averaged flat bucket (no copy back).
 
-Numerics: every rank computes the mean loss of its local shard; averaging the gradients over ranks equals the gradient
-of the global-batch mean when shards have equal size.  BatchNorm uses per-replica batch statistics by default (standard
+Numerics: every rank computes the mean loss of its local shard; the gradient of the global-batch mean is the
+shard-size-weighted mean sum_r (n_r / n) g_r.  With equal shards that is RCCL's ReduceOp.AVG; for a
+ragged global minibatch `begin(weight=n_r * world / n)` scales the rank's bucket before the collective.  BatchNorm uses per-replica batch statistics by default (standard
 DDP semantics; at the benchmark's 64 images per GPU that is exactly the reference's batch-statistics population);
 `enable_sync_bn` / `Learner.distribute(sync_bn=True)` switches to global-batch statistics (SyncBN kernels in
 csrc/batchnorm.hip), which reproduces the single-GPU reference on the same GLOBAL minibatch.
@@ -19,7 +20,8 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init_from_env', 'GradSync', 'ShardedBatches', 'enable_sync_bn', 'enable_sync_renorm', 'world_size', 'rank']
+__all__ = ['init_from_env', 'GradSync', 'ShardedBatches', 'shard_bounds', 'enable_sync_bn', 'enable_sync_renorm', 'world_size',
+           'rank']
 
 
 def world_size():
@@ -49,11 +51,29 @@ def init_from_env(backend=None):
     return rk, world, local
 
 
+def shard_bounds(n, rank_, world):
+    """Rows [a, z) of a GLOBAL minibatch of n rows that rank `rank_` of `world` owns, and whether that slice is a GHOST.
+    Balanced contiguous cut: the first n % world ranks get one row more, so shard sizes differ by at most one and no rank
+    is empty while n >= world.  With n < world the ranks beyond n would be empty — but every rank must run the step (the
+    gradient, SyncBN and renorm collectives are rank-uniform) — so such a rank re-uses row (rank mod n) as a ghost: it is
+    computed like any other row and enters the gradient average with weight 0."""
+    base, rem = divmod(n, world)
+    a = rank_ * base + min(rank_, rem)
+    z = a + base + (1 if rank_ < rem else 0)
+    if z == a and n > 0:
+        a = rank_ % n
+        return a, a + 1, True
+    return a, z, False
+
+
 class _Bucket:
     def __init__(self, params, device):
         self.params = params
         self.numel = sum(p.numel() for p in params)
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        # [gradients | one "this rank produced a gradient" flag per parameter]: the flags ride in the same collective, so
+        # every rank learns which parameters got a gradient ANYWHERE without a second message
+        self.flat = torch.zeros(self.numel + len(params), dtype=torch.float32, device=device)
+        self.flags = self.flat[self.numel:]
         self.views, o = [], 0
         for p in params:
             # same memory layout as the parameter (conv weights are stored channels_last): copies in and the optimizer's
@@ -66,6 +86,9 @@ class _Bucket:
         self.ready = [False] * len(params)
         self.handle = None
         self.averaged = False
+
+
+_FORCE_ALLREDUCE = os.environ.get('NNL_DIST_FORCE_ALLREDUCE') == '1'       # read once at import
 
 
 class GradSync:
@@ -84,6 +107,8 @@ class GradSync:
             for p in b.params:
                 if hasattr(p, '_nnl_grad_dst'):
                     del p._nnl_grad_dst
+                if hasattr(p, '_nnl_uses'):
+                    del p._nnl_uses
         self._hooks, self.buckets, self._where = [], [], {}
         params = [p for p in self.model.parameters() if p.requires_grad]
         seen, uniq = set(), []
@@ -97,25 +122,44 @@ class GradSync:
                 self.buckets.append(_Bucket(cur, p.device)); cur, cur_bytes = [], 0
         if cur:
             self.buckets.append(_Bucket(cur, cur[0].device))
+        self._use_counts = []
         for bi, b in enumerate(self.buckets):
             for pi, p in enumerate(b.params):
                 self._where[id(p)] = (bi, pi)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
                 # ops._Conv2d.backward writes the weight gradient straight into the bucket (no copy kernel) when it finds this
+                # AND the weight was used exactly once in the step's forward (`_nnl_uses[0] == 1`): a weight shared by several
+                # calls (RetinaNet's heads run on 5 pyramid levels) gets one gradient per use that autograd must SUM, so each
+                # of them needs its own buffer
                 p._nnl_grad_dst = b.views[pi]
+                p._nnl_uses = [0]
+                self._use_counts.append(p._nnl_uses)
         self._active = False
+        self.weight = 1.0
         self.direct_writes, self.steps = 0, 0           # gradients that arrived in place / backward passes (diagnostics)
 
-    def begin(self):
-        "Arm the hooks for one backward pass (Learner.train1minibatch calls this before the forward)."
+    def begin(self, weight=1.0):
+        """Arm the hooks for one backward pass (Learner.train1minibatch calls this before the forward).
+        weight: this rank's share of the global minibatch relative to an equal split, n_local * world / n_global (1.0 for
+        equal shards, 0.0 for a ghost shard): the bucket is scaled by it before the averaging collective."""
         for b in self.buckets:
             b.pending, b.ready, b.handle, b.averaged = len(b.params), [False] * len(b.params), None, False
+        for u in self._use_counts:
+            u[0] = 0
+        self._next = 0                                   # first bucket whose collective has not been issued yet
         self._active = True
+        self.weight = float(weight)
         self.steps += 1
 
     def _launch(self, b):
+        if all(b.ready):
+            b.flags.fill_(1.0)                           # (one launch; the flags were averaged / scaled by the last collective)
+        else:
+            b.flags.copy_(torch.tensor([1.0 if r else 0.0 for r in b.ready], dtype=torch.float32))
+        if self.weight != 1.0:
+            b.flat[:b.numel].mul_(self.weight)
         # NNL_DIST_FORCE_ALLREDUCE=1: issue the collective even at world_size 1 (exercises the RCCL call path on a 1-GPU box)
-        if world_size() > 1 or (dist.is_initialized() and os.environ.get('NNL_DIST_FORCE_ALLREDUCE') == '1'):
+        if world_size() > 1 or (dist.is_initialized() and _FORCE_ALLREDUCE):
             # RCCL averages inside the collective (ReduceOp.AVG); gloo has no AVG: sum, then finish() scales
             b.averaged = dist.get_backend(self.group) == 'nccl'
             op = dist.ReduceOp.AVG if b.averaged else dist.ReduceOp.SUM
@@ -134,33 +178,46 @@ class GradSync:
             b.views[pi].copy_(p.grad)
         b.ready[pi] = True
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        # collectives are issued strictly in bucket order on every rank (a rank whose data did not reach some parameter must
+        # not pair its bucket k with another rank's bucket j): launch the complete buckets at the head of the queue
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self.buckets[self._next])
+            self._next += 1
 
     def finish(self):
-        "Wait for every bucket, average, and point param.grad at the averaged bucket views."
+        """Wait for every bucket, average, and point param.grad at the averaged bucket views.
+        Every bucket is reduced on every rank every step (the collective sequence never depends on which parameters a rank's
+        data happened to reach).  A parameter that received no gradient on ANY rank keeps `grad = None`, so the optimizer skips
+        it exactly as the reference's does (torch.optim ignores grad-less parameters); one that received a gradient only on
+        other ranks gets their average — the rank learns which case it is from the flag words reduced with the bucket."""
         if not self._active:
             return
         self._active = False
         w = world_size()
-        for b in self.buckets:
-            if b.pending > 0:                          # parameters that received no gradient this step
-                if b.pending == len(b.params) and all(p.grad is None for p in b.params):
-                    continue
+        for b in self.buckets[self._next:]:
+            if b.pending > 0:                          # parameters that received no gradient on this rank this step
                 for pi, p in enumerate(b.params):
                     if not b.ready[pi]:
-                        b.views[pi].zero_() if p.grad is None else b.views[pi].copy_(p.grad)
-                self._launch(b)
+                        if p.grad is None:
+                            b.views[pi].zero_()
+                        else:                          # (a gradient that arrived outside the hooks)
+                            b.views[pi].copy_(p.grad)
+                            b.ready[pi] = True
+            self._launch(b)
+        self._next = len(self.buckets)
         for b in self.buckets:
             if b.handle is not None:
                 b.handle.wait()
                 b.handle = None
-            elif b.pending == len(b.params):
-                continue
             if w > 1 and not b.averaged:
                 b.flat.mul_(1.0 / w)
-            for p, v in zip(b.params, b.views):
-                p.grad = v
+            missing = [pi for pi in range(len(b.params)) if not b.ready[pi]]
+            anywhere = b.flags.tolist() if missing else None        # host read only in the rare grad-less case
+            for pi, (p, v) in enumerate(zip(b.params, b.views)):
+                if b.ready[pi] or anywhere[pi] > 0.0:
+                    p.grad = v
+                else:
+                    p.grad = None
 
 
 class ShardedBatches:
@@ -172,20 +229,28 @@ class ShardedBatches:
         self.batches = batches
         self.rank = rank() if rank_ is None else rank_
         self.world = world_size() if world is None else world
+        self.dp_info = None          # (rows of the last yielded shard that count, rows of its GLOBAL minibatch): Learner reads it
 
     def __len__(self):
         return len(self.batches)
 
-    def _cut(self, t):
+    def _cut(self, t, a, z):
         if isinstance(t, (list, tuple)):
-            return [self._cut(v) for v in t]
-        n = t.shape[0]
-        per = (n + self.world - 1) // self.world
-        return t[self.rank * per:min((self.rank + 1) * per, n)]
+            return [self._cut(v, a, z) for v in t]
+        return t[a:z]
+
+    @staticmethod
+    def _rows(t):
+        while isinstance(t, (list, tuple)):
+            t = t[0]
+        return t.shape[0]
 
     def __iter__(self):
         for x, y in self.batches:
-            yield self._cut(x), self._cut(y)
+            n = self._rows(y)
+            a, z, ghost = shard_bounds(n, self.rank, self.world)
+            self.dp_info = (0 if ghost else z - a, n)
+            yield self._cut(x, a, z), self._cut(y, a, z)
 
 
 def enable_sync_bn(model, group=None, comm=None):

@@ -28,7 +28,8 @@ def index_error_flag(device):
 
 def raise_if_index_error():
     """One D2H read per call: raises IndexError (torch's nn.Embedding failure) if any gather kernel since the
-    last call saw an out-of-range index.  The Learner calls this once per epoch."""
+    last call saw an out-of-range index.  The Learner calls this at the end of every epoch, evaluate() and predict()
+    (General/Learner.py `_raise_if_index_error`, which also makes the decision rank-uniform under data parallelism)."""
     for flag in _ERR_FLAGS.values():
         if int(flag.item()) != 0:
             flag.zero_()
@@ -216,6 +217,9 @@ class _Conv2d(torch.autograd.Function):
         ctx.slot = slot
         ctx.give_slot = give_slot
         ctx.grad_dst = getattr(weight, '_nnl_grad_dst', None)     # data parallel: the flat all-reduce bucket (dist.GradSync)
+        ctx.uses = getattr(weight, '_nnl_uses', None)             # forward uses of this weight in the current step
+        if ctx.uses is not None:
+            ctx.uses[0] += 1
         xn = _pad_c4(to_nhwc(_f32c(x) if x.dim() != 4 else x.float()))
         wn = _pad_c4(to_nhwc(weight.float()))
         N, H, W, C = xn.shape
@@ -303,7 +307,9 @@ class _Conv2d(torch.autograd.Function):
             ctx.slot.tensor, ctx.slot.closed = None, True
         if ctx.needs_input_grad[1]:
             dst = ctx.grad_dst
-            if dst is not None and dst.dim() == 4 and g.K == K and ctx.c_in == g.C and dst.permute(0, 2, 3, 1).is_contiguous() \
+            # in place only for a weight used ONCE this step: the gradients of a shared weight (RetinaNet heads on 5 pyramid
+            # levels) are summed by autograd and must not alias each other
+            if dst is not None and ctx.uses is not None and ctx.uses[0] == 1 and dst.dim() == 4 and g.K == K and ctx.c_in == g.C and dst.permute(0, 2, 3, 1).is_contiguous() \
                     and tuple(dst.shape) == (g.K, g.C, g.R, g.S):
                 dwn = dst.permute(0, 2, 3, 1)               # the bucket segment, viewed KRSC: the kernel writes it in place
             else:

@@ -176,3 +176,40 @@ def test_conv2d_lds_dma_staging_variant(case, monkeypatch):
     (BK 32) buffers, on plain and balanced grids."""
     monkeypatch.setenv('NNL_IGEMM_DMA', '3')
     test_conv2d_fwd_bwd(case)
+
+
+def test_shared_conv_weight_under_gradsync_is_not_aliased():
+    """under data parallelism the wgrad kernel writes dW straight into the all-reduce bucket — legal only for
+    a weight used ONCE per step.  RetinaNet's heads apply the same convolutions to 5 pyramid levels (reference
+    retinanet.py:267-268 / Vision.py:1462-1466): the five per-use gradients must be summed by autograd, not overwrite each
+    other.  GradSync at world size 1 (no collective) shows the aliasing by itself."""
+    import torch.nn as nn
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
+    torch.manual_seed(0)
+
+    class Head(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.shared = HipConv2d(16, 16, 3, padding=1)          # used on every level
+            self.once = HipConv2d(16, 16, 3, padding=1)            # used once: stays on the in-place path
+
+        def forward(self, xs):
+            return sum(self.shared(x).sum() for x in xs) + self.once(xs[0]).square().sum()
+
+    net = Head().to(DEV)
+    xs = [torch.randn(2, 16, s, s, device=DEV) for s in (16, 8, 4, 2, 1)]
+    net(xs).backward()
+    want = {n: p.grad.clone() for n, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    sync = nd.GradSync(net, bucket_mb=25.0)
+    for _ in range(2):                                                # second step: buckets re-used
+        for p in net.parameters():
+            p.grad = None
+        sync.begin()
+        net(xs).backward()
+        sync.finish()
+        for n, p in net.named_parameters():
+            assert_close(p.grad, want[n], 1e-4, 1e-4, n)
+    assert sync.direct_writes >= 2, 'the single-use convolution should still write its gradient in place'
