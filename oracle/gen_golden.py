@@ -559,7 +559,8 @@ def g12_objectdetectionnet():
     x [2,3,64,64], K=3: reg / clas activations, SSD_loss (0.5, 0.25, 2.0) and per-parameter gradient norms, in fp32 AND fp64,
     with BatchNorm in training mode (fp32-vs-fp64 gap criterion, as G6) and in eval mode (well conditioned: also gradient
     slices).  The constructor's `vmods.retinanet.retinanet()` loads a COCO checkpoint that is an LFS pointer in the snapshot
-    (retinanet.py:430-435): it is replaced HERE by the same architecture with seeded weights (synth.fill_module_)."""
+    (retinanet.py:430-435): it is replaced HERE by the same architecture with seeded weights (synth.fill_detection_net_:
+    every activation O(1), so the comparison is not dominated by cancellation of ~1e3-sized head activations)."""
     RN = R['Applications.VisionModels.retinanet']
     V = R['Applications.Vision']
     RN.retinanet = lambda *a, **k: RN.RetinaNet(80, RN.Bottleneck, [3, 4, 6, 3])
@@ -575,7 +576,7 @@ def g12_objectdetectionnet():
     for tag, dtype in [('f32', torch.float32), ('f64', torch.float64)]:
         torch.manual_seed(0)
         net = V.ObjectDetectionNet(K)
-        synth.fill_module_(net)
+        synth.fill_detection_net_(net)          # well-conditioned seeded weights: activations stay O(1) in eval mode too
         net = net.to(dtype)
         sd = dict(net.named_parameters())
         if tag == 'f32':

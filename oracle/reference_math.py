@@ -135,9 +135,9 @@ def smoothL1_loss_retina(anchs, pred_shift, target):
     tx, ty = target[:, 0] + 0.5 * tw, target[:, 1] + 0.5 * th
     tw, th = tw.clamp(min=1), th.clamp(min=1)
     true = torch.stack(((tx - ax) / aw, (ty - ay) / ah, torch.log(tw / aw), torch.log(th / ah))).t()
-    true = true / torch.tensor([[0.1, 0.1, 0.2, 0.2]])
+    true = true / torch.tensor([[0.1, 0.1, 0.2, 0.2]], dtype=true.dtype)
     diff = torch.abs(true - pred_shift)
-    losses = 0.5 * 9 * diff.pow(2) * (diff < 1 / 9).float() + (diff - 0.5 / 9) * (diff >= 1 / 9).float()
+    losses = 0.5 * 9 * diff.pow(2) * (diff < 1 / 9).to(diff.dtype) + (diff - 0.5 / 9) * (diff >= 1 / 9).to(diff.dtype)
     return losses.mean()
 
 
@@ -145,13 +145,13 @@ def ssd_loss(anchors, reg, clas, BBoxes, Cats, beta=0.5, alpha=0.25, gamma=2.0):
     """(total, reg_loss, clas_loss) of a batch: per image strip the -1 padding, match, build the one-hot targets of
     the positive anchors, focal over pos+neg anchors, smooth-L1 over pos anchors; batch means (Vision.py:1568-1644)."""
     bs, K = len(BBoxes), clas.shape[2]
-    reg_loss, clas_loss = torch.zeros(()), torch.zeros(())
+    reg_loss, clas_loss = torch.zeros((), dtype=clas.dtype), torch.zeros((), dtype=clas.dtype)
     for i in range(bs):
         keep = Cats[i] >= 0
         boxes, cats = BBoxes[i][keep], Cats[i][keep]
         state = match_anchors_objects(boxes, anchors)
         pos, used = state >= 0, state != -2
-        targ = torch.zeros(len(anchors), K)
+        targ = torch.zeros(len(anchors), K, dtype=clas.dtype)
         if pos.any():
             targ[pos.nonzero().view(-1), cats[state[pos]]] = 1
         clas_loss = clas_loss + focal_loss_retina(clas[i][used], targ[used], alpha, gamma)

@@ -30,3 +30,21 @@ def fill_module_(module, seed=0):
 
 def synth_input(shape, tag, scale=1.0):
     return torch.from_numpy(synth_array(shape, 100003 + tag, scale))
+
+
+def fill_detection_net_(net, seed=0):
+    """fill_module_ + the conditioning an ObjectDetectionNet needs to keep every activation O(1) WITHOUT relying on batch
+    statistics (eval-mode BatchNorm is an affine map): the closing BatchNorm of each Bottleneck (`*.bn3.weight`) is scaled by
+    0.2 so 16 residual blocks do not double the signal each; the two head output convolutions get small weights and the
+    classifier's output bias sits at -2 (sigmoid outputs ~0.1, unsaturated).  Same closed-form values on the reference side
+    (oracle/gen_golden.py g12) and on the oracle / product side (tests)."""
+    fill_module_(net, seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith('bn3.weight'):
+                p.mul_(0.2)
+            elif name in ('classifier.output.weight', 'regressor.output.weight'):
+                p.mul_(0.25)
+            elif name == 'classifier.output.bias':
+                p.sub_(2.0)
+    return net
