@@ -1,86 +1,697 @@
-"""Headline benchmark: Learner.train1minibatch on ResNet-34 (+ default head), 224x224, bs=64 per GPU, fp32,
-synthetic data, SGD-momentum — BASELINE.json configs[1] ("DogsCats ResNet-34 classifier, 224x224 bs=64").
+"""Benchmark of the Learner.fit() hot path (BASELINE.json): Learner.train1minibatch — forward + loss + backward +
+Optimizer.step + the per-step loss read-back — on synthetic device-resident batches of the five BASELINE configs.
 
-    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0): whole-job images/s, ms/step, plus
-  roofline     — the dominant kernel family (fp32-MFMA implicit-GEMM conv fwd+dgrad+wgrad): algorithmic FLOPs per
-                 launch / average launch duration, measured with HIP events recorded by libnnl_hip.so on the launch
-                 stream during K extra steps of the same command, against the dense fp32 MFMA peak (157.3 TFLOP/s);
-  cpu_baseline — the CPU oracle (oracle/reference_nets.py, a torch-CPU restatement pinned to reference goldens; the
-                 reference's own Python cannot travel to the GPU box) running the SAME step on the host cores.
+N > 1 without WORLD_SIZE in the environment: this process starts N worker processes itself (one rank per GPU, RCCL) BEFORE it
+touches the GPU and relays rank 0's line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+launcher's environment is used instead.  Rank 0 prints ONE JSON line:
+
+  value / ms_per_step  headline, BASELINE configs[1]: ResNet-34 + default head, 224x224, 64 images PER GPU (weak scaling), fp32
+  roofline             dominant kernel family of the headline (fp32-MFMA implicit-GEMM conv fwd + dgrad + wgrad): algorithmic
+                       FLOPs per launch / average launch duration from HIP events that libnnl_hip.so records on the launch
+                       stream during extra steps of the same command, against the dense fp32 MFMA peak (157.3 TFLOP/s)
+  cpu_baseline         (N = 1) the CPU oracle (oracle/: torch-CPU restatement pinned to reference goldens — the reference's own
+                       Python cannot travel to the GPU box) running the SAME step on the host cores
+  strong               (N > 1) the same model at GLOBAL batch 64 (64/N images per GPU): the north-star's strong-scaling case
+  dp                   (N > 1) ranks_seen (an RCCL all-reduce of ones), gradient buckets, stand-alone all-reduce time per step,
+                       exposed communication and overlap fraction
+  strong_scaling_proxy (N = 1) step time at bs 8 / 16 / 32 on one GPU: t(64) / t(bs) is the compute-side ceiling of strong
+                       scaling at 8 / 4 / 2 GPUs
+  configs              the other four BASELINE configs (collab bs 64, Rossmann-shape MLP bs 1024, AWD-LSTM bs 64 bptt 70
+                       V 47 343, RetinaNet R50-FPN 512x512 bs 16), each with ms/step, whole-job samples/s, roofline, cpu_baseline
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 CONV_GFLOP_PER_IMAGE = 21.98           # 3 x 2 x 3.6638 GMAC (fwd + dgrad + wgrad)
+LM_MFLOP_PER_TOKEN = 234.8             # 3 x 2 x 39.13 MMAC
+RETINA_GFLOP_PER_IMAGE = 325.4         # 3 x 2 x 54.235 GMAC
+RETINA_LOSS_BYTES_PER_ANCHOR = 224
+FLOP_KINDS = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'gemm', 'lstm')
+ROSSMANN_CARDS = [1116, 5, 4, 13, 53, 13, 4, 8, 32, 23, 27, 24, 28, 9, 5, 5] + [10] * 16
 
 
-class SynthData:
-    """Device-resident synthetic batches honouring the Learner's data protocol."""
-    target_type = 'single_label'
-    categories = {0: 'cat', 1: 'dog'}
-
-    def __init__(self, bs, sz, n_batches, device, seed):
-        g = torch.Generator(device=device).manual_seed(seed)
-        self.bs, self.sz = bs, (sz, sz)
-        self.batches = [(torch.randn(bs, 3, sz, sz, device=device, generator=g),
-                         torch.randint(0, 2, (bs,), device=device, generator=g)) for _ in range(n_batches)]
-        self.train_dl = self.batches
-        self.val_dl = self.batches[:1]
+# =====================================================================================================================
+# self-launch: N ranks from a plain `python bench.py --gpus N`
+# =====================================================================================================================
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
-def build_learner(device, bs, sz, seed):
+def self_launch(n):
+    """Start n copies of this command as child processes, rank r on GPU r, and relay rank 0's stdout.  The parent never
+    initialises the GPU (no HIP call, no device query), and nothing is exec'ed over a process that has."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:                         # one rank failed: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
+# =====================================================================================================================
+# workloads
+# =====================================================================================================================
+class Data:
+    "minimal data object of the Learner protocol (train_dl / val_dl / bs / target_type) over device-resident batches"
+
+    def __init__(self, batches, bs, target_type, **kw):
+        self.train_dl, self.val_dl, self.bs, self.target_type = batches, batches[:1], bs, target_type
+        self.batches = batches
+        self.__dict__.update(kw)
+
+
+class Workload:
+    def __init__(self, name, learner, batches, lr, unit, units_per_step, **step_kw):
+        self.name, self.learner, self.batches, self.lr, self.unit = name, learner, batches, lr, unit
+        self.units_per_step, self.step_kw = units_per_step, step_kw          # units per step on THIS rank
+        self.loss = None
+
+    def step(self, i):
+        x, y = self.batches[i % len(self.batches)]
+        self.loss = self.learner.train1minibatch(x, y, self.lr, **self.step_kw)
+        return self.loss
+
+
+def _learner_cls():
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    Learner.verbose = False
+    return Learner
+
+
+def _finish(learner, world):
+    if world > 1 or os.environ.get('NNL_BENCH_FORCE_DIST') == '1':
+        learner.distribute(equal_shards=True)          # synthetic batches: every rank always holds a full shard
+    learner.model.train()
+    return learner
+
+
+def resnet34_workload(device, bs, seed, world, sz=224, sync_bn=False):
+    "BASELINE configs[1]: DogsCats ResNet-34 classifier (Vision.py:1244-1337), SGD momentum, CE loss"
     from neuralnetworklibrary_amd.Applications import Vision as V
-    from neuralnetworklibrary_amd.General.Core import set_default_device
-    set_default_device(device)
-    torch.manual_seed(seed)
-    data = SynthData(bs, sz, 4, device, seed)
+    torch.manual_seed(seed % 1000)                   # model init: the same on every rank (seed = base + 1000 * rank)
+    g = torch.Generator(device=device).manual_seed(seed)
+    batches = [(torch.randn(bs, 3, sz, sz, device=device, generator=g), torch.randint(0, 2, (bs,), device=device, generator=g))
+               for _ in range(4)]
+    data = Data(batches, bs, 'single_label', sz=(sz, sz), categories={0: 'cat', 1: 'dog'})
     net = V.ImageClassificationNet(data, V.models.resnet34())
     learner = V.ImageLearner('/tmp/nnl_bench', data, net, optimizer='SGD_Mom')
     learner.init_optimizer(wd=1e-4)
-    return learner, data
+    _finish(learner, world)
+    if sync_bn and world > 1:
+        from neuralnetworklibrary_amd import dist as nd
+        nd.enable_sync_bn(learner.model)
+    return Workload('resnet34', learner, batches, [1e-3, 3e-3, 1e-2], 'images/s', bs)
 
 
-def cpu_baseline(bs, sz, steps=2):
-    """The same train step on the host cores with the CPU oracle (plain torch fp32 eager + restated Optimizer.step)."""
-    from oracle import reference_math as RM
-    from oracle import reference_nets as RN
-    # the GPU box shares its host: 16 cores is the CPU share of a 1-GPU slot (more threads thrash: 256 threads
-    # measured 116 s/step vs ~4 s/step on 8 cores)
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+def collab_workload(device, bs, seed, world):
+    "BASELINE configs[0] shape on the GPU: ML-100K CollabFilterNet (CollabFiltering.py:168-213), D=30, Adam, wd 1e-4"
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterNet
+    torch.manual_seed(seed % 1000)                   # model init: the same on every rank (seed = base + 1000 * rank)
+    g = torch.Generator(device=device).manual_seed(seed)
+    batches = [(torch.stack([torch.randint(0, 943, (bs,), device=device, generator=g),
+                             torch.randint(0, 1682, (bs,), device=device, generator=g)], 1),
+                torch.randint(1, 6, (bs,), device=device, generator=g).float()) for _ in range(4)]
+    net = CollabFilterNet(943, 1682, 30, [0.8, 5.2])
+    learner = _learner_cls()('/tmp/nnl_bench', Data(batches, bs, 'cont'), net, optimizer='Adam')
+    learner.init_optimizer(wd=1e-4)
+    return Workload('collab', _finish(learner, world), batches, 1e-2, 'samples/s', bs)
+
+
+def tabular_workload(device, bs, seed, world):
+    "BASELINE configs[2]: Rossmann-shape StructuredDataNet (StructuredData.py:979-1096), fc [1000,500,1], Adam, wd 1e-3"
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    torch.manual_seed(seed % 1000)                   # model init: the same on every rank (seed = base + 1000 * rank)
+    rs = np.random.RandomState(seed)
+    n_cont, batches = 14, []
+    for _ in range(4):
+        xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=bs) for c in ROSSMANN_CARDS], 1).astype(np.int64)).to(device)
+        xcont = torch.from_numpy(rs.standard_normal((bs, n_cont)).astype(np.float32)).to(device)
+        y = torch.from_numpy((5 + 7 * rs.rand(bs)).astype(np.float32)).to(device)
+        batches.append(([xcat, xcont], y))
+    net = StructuredDataNet('cont', len(ROSSMANN_CARDS), n_cont, [{i: i for i in range(c)} for c in ROSSMANN_CARDS],
+                            [1000, 500, 1], output_range=[5, 12], dropout_levels=(0.04, 0.04, [0, 0.5, 0.25]))
+    learner = _learner_cls()('/tmp/nnl_bench', Data(batches, bs, 'cont'), net, optimizer='Adam')
+    learner.init_optimizer(wd=1e-3)
+    return Workload('tabular', _finish(learner, world), batches, [1e-3, 1e-3], 'samples/s', bs)
+
+
+LM_V, LM_BPTT = 47343, 70
+
+
+def lm_workload(device, bs, seed, world):
+    "BASELINE configs[3]: AWD-LSTM LanguageModelNet 400/1150/3 (Text.py:611-702), V=47 343, bptt 70, Adam(0.8, 0.99), RegSeqCE(2,1)"
+    from neuralnetworklibrary_amd.Applications.Text import LanguageModelNet, RegSeqCrossEntropyLoss, _Vocab
+    torch.manual_seed(seed % 1000)                   # model init: the same on every rank (seed = base + 1000 * rank)
+    stoi = {i: i for i in range(LM_V)}
+    stoi['_pad_'] = 1
+    del stoi[1]
+    g = torch.Generator(device=device).manual_seed(seed)
+    stream_ = torch.randint(4, LM_V, (bs, LM_BPTT * 4 + 1), device=device, generator=g)
+    batches = [(stream_[:, i * LM_BPTT:(i + 1) * LM_BPTT].contiguous(), stream_[:, i * LM_BPTT + 1:(i + 1) * LM_BPTT + 1].contiguous())
+               for i in range(4)]
+    net = LanguageModelNet(_Vocab(stoi, bs))
+    learner = _learner_cls()('/tmp/nnl_bench', Data(batches, bs, 'lang_model'), net, optimizer='Adam',
+                             loss_func=RegSeqCrossEntropyLoss(2.0, 1.0))
+    learner.init_optimizer(wd=1e-6, clip=0.4)
+    return Workload('lm', _finish(learner, world), batches, [1e-3, 1e-3], 'tokens/s', bs * LM_BPTT, betas_batch=(0.8, 0.99))
+
+
+def _retina_targets(rs, bs, M=8):
+    boxes = -np.ones((bs, M, 4), np.float32)
+    cats = -np.ones((bs, M), np.int64)
+    for i in range(bs):
+        m = rs.randint(1, M + 1)
+        xy, wh = rs.uniform(0, 300, (m, 2)), rs.uniform(30, 210, (m, 2))
+        boxes[i, :m] = np.concatenate([xy, xy + wh], 1)
+        cats[i, :m] = rs.randint(0, 20, m)
+    return boxes, cats
+
+
+def retina_workload(device, bs, seed, world, sz=512):
+    "BASELINE configs[4]: ObjectDetectionNet(20) = ResNet-50 + FPN + heads (Vision.py:1382-1471), SSD_loss(.5,.25,2), SGD momentum"
+    from neuralnetworklibrary_amd.Applications.Vision import ObjectDetectionNet, SSD_loss
+    torch.manual_seed(seed % 1000)                   # model init: the same on every rank (seed = base + 1000 * rank)
+    rs = np.random.RandomState(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
+    batches = []
+    for _ in range(2):
+        boxes, cats = _retina_targets(rs, bs)
+        batches.append((torch.randn(bs, 3, sz, sz, device=device, generator=g),
+                        [torch.from_numpy(boxes).to(device), torch.from_numpy(cats).to(device)]))
+    net = ObjectDetectionNet(20)
+    learner = _learner_cls()('/tmp/nnl_bench', Data(batches, bs, 'bbox'), net, optimizer='SGD_Mom', loss_func=SSD_loss(0.5, 0.25, 2.0))
+    learner.init_optimizer(wd=1e-4)
+    return Workload('retinanet', _finish(learner, world), batches, [1e-4, 1e-3, 1e-3], 'images/s', bs)
+
+
+# =====================================================================================================================
+# measurement
+# =====================================================================================================================
+class Clock:
+    "barrier + device synchronise on both sides of a timed region; the time is the MAX over ranks"
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize()
+
+    def timed(self, fn, warmup, steps):
+        for i in range(warmup):
+            fn(i)
+        self.sync()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            t = torch.tensor([dt], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+
+def profile_kinds(wl, n):
+    "n extra steps with per-launch HIP events on the launch stream -> {kind: {launches, ms, work}} (nnl_prof_*)"
+    from neuralnetworklibrary_amd import _lib
+    _lib.prof_enable(True)
+    for i in range(n):
+        wl.step(i)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    return {k: v for k, v in _lib.prof_collect().items() if v['launches']}
+
+
+def by_kind(prof, n):
+    return {k: {'ms_per_step': round(v['ms'] / max(n, 1), 3),
+                ('tflops' if k in FLOP_KINDS else 'tbytes_per_s'): round(v['work'] / (v['ms'] * 1e-3) / 1e12, 3) if v['ms'] > 0 else None}
+            for k, v in prof.items()}
+
+
+def mfma_roofline(prof, n, kinds=('conv_fwd', 'conv_dgrad', 'conv_wgrad'), kernel=''):
+    ms = sum(prof[k]['ms'] for k in kinds if k in prof)
+    flop = sum(prof[k]['work'] for k in kinds if k in prof)
+    launches = sum(prof[k]['launches'] for k in kinds if k in prof)
+    achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel,
+            'launches_per_step': launches / max(n, 1), 'avg_launch_ms': ms / max(launches, 1),
+            'flop_per_launch': flop / max(launches, 1), 'kernel_ms_per_step': ms / max(n, 1), 'by_kind': by_kind(prof, n)}
+
+
+def committed_traffic(bs, sz, world):
+    """HBM-side bytes per launch of the dominant kernel family: NOT measured by this run — it comes from separate
+    `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this same command (tools/pmc_traffic.py; gfx950 corrections applied),
+    committed under profiles/.  Reported only for the configuration those passes profiled."""
+    for name in ('r2_traffic.json', 'r1_traffic.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                t = json.load(f)
+        except Exception:
+            continue
+        if (bs, sz, world) == (t.get('bs', 64), t.get('sz', 224), t.get('gpus', 1)):
+            return round(t['traffic_bytes_per_launch']), 'profiles/%s (rocprofv3 --pmc passes of this command; a committed figure, not measured in this run)' % name
+    return None, None
+
+
+def host_info():
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {'host_cores': os.cpu_count(), 'cpu_model': model}
+
+
+# ---- CPU baselines: the oracle's restatement of the same step on the host cores (rank 0, N = 1 only) ------------------
+def _cpu_threads():
+    # the GPU box shares its host: 16 cores is the CPU share of a 1-GPU slot (more threads thrash: 256 threads measured
+    # 116 s/step vs ~4 s/step on 8 cores)
+    n = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(n)
+    return n
+
+
+def _cpu_time(step, steps):
+    step()                                                  # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    return (time.time() - t0) / steps
+
+
+def _sgd_adam_step(RM, params, state, kind, lr, wd, **kw):
+    RM.optimizer_step(params, [p.grad for p in params], state, [lr] * len(params), [wd] * len(params), kind, **kw)
+
+
+def cpu_baseline_resnet(bs, sz, steps=2):
+    from oracle import reference_math as RM, reference_nets as RN
+    threads = _cpu_threads()
     torch.manual_seed(0)
     net = RN.ImageClassificationNet(RN.resnet34(), 2, 512).train()
-    params = [p for p in net.parameters()]
+    params = list(net.parameters())
     state = RM.OptimState(params)
     x, y = torch.randn(bs, 3, sz, sz), torch.randint(0, 2, (bs,))
-    times = []
-    for i in range(steps + 1):
-        t0 = time.time()
+
+    def step():
         for p in params:
             p.grad = None
         loss = torch.nn.functional.cross_entropy(net(x), y)
         loss.backward()
-        RM.optimizer_step(params, [p.grad for p in params], state, [1e-2] * len(params), [1e-4] * len(params), 'sgd')
+        _sgd_adam_step(RM, params, state, 'sgd', 1e-2, 1e-4)
         loss.item()
-        if i > 0:
-            times.append(time.time() - t0)
-    dt = sum(times) / len(times)
-    return {'value': bs / dt, 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d steps of the same bs=%d %dx%d ResNet-34 train step (after 1 warm-up), torch-CPU oracle' % (steps, bs, sz, sz),
-            'ms_per_step': dt * 1e3}
+    dt = _cpu_time(step, steps)
+    return dict({'value': bs / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+                 'sample': '%d steps of the same bs=%d %dx%d ResNet-34 train step (after 1 warm-up), torch-CPU oracle' % (steps, bs, sz, sz),
+                 'ms_per_step': dt * 1e3}, **host_info())
 
 
-FLOP_KINDS = ('conv_fwd', 'conv_dgrad', 'conv_wgrad', 'gemm', 'lstm')
+def cpu_baseline_collab(bs, steps=200):
+    from oracle import reference_math as RM, reference_nets as RN
+    threads = _cpu_threads()
+    torch.manual_seed(0)
+    net = RN.CollabFilterNet(943, 1682, 30, [0.8, 5.2])
+    params = list(net.parameters())
+    state = RM.OptimState(params)
+    x = torch.stack([torch.randint(0, 943, (bs,)), torch.randint(0, 1682, (bs,))], 1)
+    y = torch.randint(1, 6, (bs,)).float()
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = RM.mse_loss(net(x), y)
+        loss.backward()
+        _sgd_adam_step(RM, params, state, 'adam', 1e-2, 1e-4)
+        loss.item()
+    dt = _cpu_time(step, steps)
+    return {'value': bs / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port', 'ms_per_step': dt * 1e3,
+            'sample': '%d steps of the same bs=%d ML-100K-shape step, torch-CPU oracle' % (steps, bs)}
+
+
+def cpu_baseline_tabular(bs, steps=10):
+    from oracle import reference_math as RM, reference_nets as RN
+    threads = _cpu_threads()
+    torch.manual_seed(0)
+    rs = np.random.RandomState(0)
+    net = RN.StructuredDataNet('cont', [(c, RN.embedding_dim(c)) for c in ROSSMANN_CARDS], 14, [1000, 500, 1], [5, 12],
+                               (0.04, 0.04, [0, 0.5, 0.25])).train()
+    params = list(net.parameters())
+    state = RM.OptimState(params)
+    xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=bs) for c in ROSSMANN_CARDS], 1).astype(np.int64))
+    xcont, y = torch.randn(bs, 14), 5 + 7 * torch.rand(bs)
+
+    def step():
+        for p in params:
+            p.grad = None
+        loss = RM.mse_loss(net(xcat, xcont), y)
+        loss.backward()
+        _sgd_adam_step(RM, params, state, 'adam', 1e-3, 1e-3)
+        loss.item()
+    dt = _cpu_time(step, steps)
+    return {'value': bs / dt, 'unit': 'samples/s', 'cores': threads, 'kind': 'port', 'ms_per_step': dt * 1e3,
+            'sample': '%d steps of the same bs=%d Rossmann-shape step, torch-CPU oracle' % (steps, bs)}
+
+
+def cpu_baseline_lm(streams=16, steps=1):
+    from oracle import reference_math as RM, reference_text as RT
+    threads = _cpu_threads()
+    torch.manual_seed(0)
+    net = RT.LanguageModelNet(LM_V, 1, streams)
+    params = list(net.parameters())
+    state = RM.OptimState(params)
+    x = torch.randint(4, LM_V, (streams, LM_BPTT))
+    y = torch.randint(4, LM_V, (streams, LM_BPTT))
+    keep = lambda shape, p: torch.bernoulli(torch.full(shape, 1 - p)) / (1 - p)
+    sizes = [400, 1150, 1150, 400]
+
+    def step():
+        for p in params:
+            p.grad = None
+        masks = {'emb_rows': keep((LM_V, 1), 0.035), 'emb_locked': keep((1, streams, 400), 0.175),
+                 'weights': [keep((4 * sizes[i + 1], sizes[i + 1]), 0.14) for i in range(3)],
+                 'hidden': [keep((1, streams, sizes[i + 1]), 0.105) for i in range(3)]}
+        loss = RT.reg_seq_cross_entropy(net(x, masks, keep((1, streams, 400), 0.07)), y, 2.0, 1.0)[0]
+        loss.backward()
+        _sgd_adam_step(RM, params, state, 'adam', 1e-3, 1e-6, betas=(0.8, 0.99), clip=0.4)
+        loss.item()
+    dt = _cpu_time(step, steps)
+    return {'value': streams * LM_BPTT / dt, 'unit': 'tokens/s', 'cores': threads, 'kind': 'port', 'ms_per_step': dt * 1e3,
+            'sample': '%d step(s) of the full-size model (400/1150/3, V=%d, bptt %d) on %d of the 64 streams (after 1 warm-up), '
+                      'torch-CPU oracle' % (steps, LM_V, LM_BPTT, streams)}
+
+
+def cpu_baseline_retina(bs=1, sz=512, steps=1):
+    from oracle import reference_math as RM, reference_nets as RN
+    threads = _cpu_threads()
+    torch.manual_seed(0)
+    net = RN.ObjectDetectionNet(20).train()
+    with torch.no_grad():                                    # the reference's head initialisation (Vision.py:1425-1428)
+        net.classifier.output.weight.zero_(); net.classifier.output.bias.fill_(-float(np.log(99.0)))
+        net.regressor.output.weight.zero_(); net.regressor.output.bias.zero_()
+    params = list(net.parameters())
+    state = RM.OptimState(params)
+    x = torch.randn(bs, 3, sz, sz)
+    boxes, cats = _retina_targets(np.random.RandomState(0), bs)
+    B, Cc = torch.from_numpy(boxes), torch.from_numpy(cats)
+
+    def step():
+        for p in params:
+            p.grad = None
+        anchors, reg, clas = net(x)
+        loss = RM.ssd_loss(anchors, reg, clas, B, Cc, 0.5, 0.25, 2.0)[0]
+        loss.backward()
+        _sgd_adam_step(RM, params, state, 'sgd', 1e-3, 1e-4)
+        loss.item()
+    dt = _cpu_time(step, steps)
+    return {'value': bs / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'ms_per_step': dt * 1e3,
+            'sample': '%d step(s) of the same RetinaNet R50-FPN %dx%d train step on %d of the 16 images (after 1 warm-up), '
+                      'torch-CPU oracle' % (steps, sz, sz, bs)}
+
+
+# ---- the other four configs -----------------------------------------------------------------------------------------
+def _n_params(model):
+    seen, n = set(), 0
+    for p in model.parameters():
+        if id(p) not in seen and p.requires_grad:
+            seen.add(id(p)); n += p.numel()
+    return n
+
+
+def run_config(name, device, world, rank, clock, steps, warmup, cpu):
+    """One of the non-headline configs: weak scaling (the named batch PER GPU), K timed steps, a HIP-event profile of 3 more,
+    the roofline SURVEY.md §8(d) prescribes for it and (N = 1) a bounded CPU-oracle baseline."""
+    seed = 1234 + {'collab': 0, 'tabular': 2, 'lm': 3, 'retinanet': 4}[name] + 1000 * rank
+    if name == 'collab':
+        wl, bs = collab_workload(device, 64, seed, world), 64
+    elif name == 'tabular':
+        wl, bs = tabular_workload(device, 1024, seed, world), 1024
+    elif name == 'lm':
+        wl, bs = lm_workload(device, 64, seed, world), 64
+    else:
+        wl, bs = retina_workload(device, 16, seed, world), 16
+    out = {'workload': {'collab': 'MovieLens-100K CollabFiltering EmbeddingDotBias D=30, bs=64 per GPU, Adam',
+                        'tabular': 'Rossmann-shape StructuredData MLP (32 embeddings + 14 continuous -> 1000 -> 500 -> 1), bs=1024 per GPU, Adam',
+                        'lm': 'IMDB AWD-LSTM language model 400/1150/3, V=47343, bptt=70, bs=64 per GPU, Adam, RegSeqCrossEntropyLoss(2,1)',
+                        'retinanet': 'Pascal RetinaNet (ResNet-50 FPN + FocalLoss / smooth-L1), 512x512, bs=16 per GPU, SGD momentum'}[name],
+           'unit': wl.unit, 'steps': steps, 'dtype': 'f32', 'scaling': 'weak'}
+    dt = clock.timed(wl.step, warmup, steps)
+    ms = dt / steps * 1e3
+    out.update(ms_per_step=round(ms, 3), value=round(wl.units_per_step * world * steps / dt, 1), last_loss=wl.loss)
+    if name in ('collab', 'tabular') and world == 1:        # launch-bound heads: the captured whole-step hipGraph (Learner.use_graphs)
+        wl.learner.use_graphs(True)
+        dtg = clock.timed(wl.step, warmup + 3, steps)
+        wl.learner.use_graphs(False)
+        out['hipgraph_step'] = {'ms_per_step': round(dtg / steps * 1e3, 3), 'value': round(wl.units_per_step * steps / dtg, 1)}
+        ms_best = min(ms, dtg / steps * 1e3)
+    else:
+        ms_best = ms
+    n_prof = 3
+    prof = profile_kinds(wl, n_prof)
+    n_par = _n_params(wl.learner.model)
+    if name == 'lm':
+        rf = mfma_roofline(prof, n_prof, FLOP_KINDS, 'igemm_taps / igemm_wgrad (input, decoder and weight-gradient GEMMs) + the LSTM recurrence kernels')
+        rf['algorithmic_tflop_per_step'] = LM_MFLOP_PER_TOKEN * 1e6 * wl.units_per_step / 1e12
+        rf['whole_step_tflops'] = round(rf['algorithmic_tflop_per_step'] / (ms * 1e-3), 2)
+    elif name == 'retinanet':
+        rf = mfma_roofline(prof, n_prof, FLOP_KINDS, 'igemm_taps / igemm_wgrad (ResNet-50 + FPN + head convolutions: fwd, dgrad, wgrad)')
+        rf['algorithmic_tflop_per_step'] = RETINA_GFLOP_PER_IMAGE * 1e9 * bs / 1e12
+        rf['whole_step_tflops'] = round(rf['algorithmic_tflop_per_step'] / (ms * 1e-3), 2)
+        if 'retina_loss' in prof:
+            lb = RETINA_LOSS_BYTES_PER_ANCHOR * 49104.0 * bs
+            lms = prof['retina_loss']['ms'] / n_prof
+            rf['loss_kernels'] = {'bound': 'hbm', 'achieved': round(lb / (lms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                  'frac': round(lb / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'ms_per_step': round(lms, 4),
+                                  'kernel': 'retina_fwd + retina_finalize + retina_bwd (224 B/anchor algorithmic)'}
+    else:
+        # launch / HBM-latency bound — judged by algorithmic bytes per step over the WHOLE step time
+        if name == 'collab':
+            alg = 516.0 * bs + n_par * 28.0
+            kern = 'embdotbias_fwd/bwd + fused Adam over the dense tables (516 B/sample + 28 B/parameter)'
+        else:
+            alg = n_par * 28.0 + bs * (203 + 3 * 1000 + 3 * 500) * 4.0 * 2 + bs * 189 * 4.0 * 2
+            kern = 'tab_gather/scatter + igemm linears + BN1d + fused Adam (weights+Adam state 28 B/param, activations, gathers)'
+        gbs = alg / (ms_best * 1e-3) / 1e9
+        rf = {'bound': 'hbm', 'achieved': round(gbs, 2), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 5),
+              'traffic': None, 'kernel': kern, 'algorithmic_bytes_per_step': alg,
+              'note': 'latency-bound at this batch size: achieved = algorithmic bytes / whole step time (best of eager and hipGraph)',
+              'kernel_ms_per_step': round(sum(v['ms'] for v in prof.values()) / n_prof, 4), 'by_kind': by_kind(prof, n_prof)}
+    out['roofline'] = rf
+    del wl
+    torch.cuda.empty_cache()
+    if cpu:
+        out['cpu_baseline'] = {'collab': lambda: cpu_baseline_collab(64), 'tabular': lambda: cpu_baseline_tabular(1024),
+                               'lm': cpu_baseline_lm, 'retinanet': cpu_baseline_retina}[name]()
+    return out
+
+
+# =====================================================================================================================
+# data-parallel diagnostics (N > 1)
+# =====================================================================================================================
+def dp_diagnostics(wl, clock, dist, steps, ms_dp):
+    """Stand-alone all-reduce time of one step's gradient buckets, the step time with the collectives removed, and from the
+    two the communication that stays exposed: overlap = 1 - exposed / standalone."""
+    gs = wl.learner.grad_sync
+    reps = 5
+
+    def allreduce_only(_):
+        hs = [dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, async_op=True) for b in gs.buckets]
+        for h in hs:
+            h.wait()
+    ar_ms = clock.timed(allreduce_only, 2, reps) / reps * 1e3
+    learner = wl.learner
+    learner.grad_sync = None
+    learner.optimizer.attach_grad_sync(None)
+    ms_nosync = clock.timed(wl.step, 2, steps) / steps * 1e3
+    learner.grad_sync = gs
+    learner.optimizer.attach_grad_sync(gs)
+    exposed = max(ms_dp - ms_nosync, 0.0)
+    return {'grad_buckets': len(gs.buckets), 'grad_mbytes': round(sum(b.numel for b in gs.buckets) * 4 / 2 ** 20, 1),
+            'grads_written_in_place': '%d of %d tensors per step' % (gs.direct_writes // max(gs.steps, 1), sum(len(b.params) for b in gs.buckets)),
+            'allreduce_ms_per_step_standalone': round(ar_ms, 3), 'ms_per_step_without_allreduce': round(ms_nosync, 3),
+            'exposed_comm_ms_per_step': round(exposed, 3),
+            'overlap_frac': round(1.0 - exposed / ar_ms, 3) if ar_ms > 0 else None}
+
+
+# =====================================================================================================================
+# dry run (CPU, gloo): the launch / rendezvous / timing / JSON protocol without the HIP path
+# =====================================================================================================================
+def dry_run_worker(args, world, rank):
+    import torch.distributed as dist
+    import torch.nn as nn
+    from neuralnetworklibrary_amd.General.Core import make_model_basic, set_default_device
+    set_default_device('cpu')
+    torch.set_num_threads(1)
+    device = torch.device('cpu')
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+    clock = Clock(dist if world > 1 else None, device)
+    out = {}
+    for tag, bs in (('weak', args.bs), ('strong', max(args.bs // world, 1))):
+        torch.manual_seed(0)
+        net = make_model_basic(nn.Sequential(nn.Linear(16, 32), nn.ReLU(), nn.Linear(32, 1), nn.Flatten(0)))
+        g = torch.Generator().manual_seed(rank)
+        batches = [(torch.randn(bs, 16, generator=g), torch.randn(bs, generator=g)) for _ in range(4)]
+        learner = _learner_cls()('/tmp/nnl_bench_dry', Data(batches, bs, 'cont'), net, optimizer='SGD_Mom')
+        learner.init_optimizer(wd=1e-4)
+        if world > 1:
+            learner.distribute(equal_shards=True)
+        wl = Workload('dry', learner, batches, 1e-2, 'samples/s', bs)
+        dt = clock.timed(wl.step, args.warmup, args.steps)
+        out[tag] = {'global_batch': bs * world, 'per_gpu_batch': bs, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+                    'value': round(bs * world * args.steps / dt, 2)}
+    if rank == 0:
+        print(json.dumps({'metric': 'DRY RUN (CPU, gloo): launch protocol only, not a measurement', 'dry_run': True,
+                          'value': out['weak']['value'], 'unit': 'samples/s', 'n_gpus': world, 'ranks_seen': int(ones.item()),
+                          'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': out['weak']['ms_per_step'],
+                          'higher_is_better': True, 'scaling': 'weak', 'strong': out['strong']}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# =====================================================================================================================
+def worker(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
+    if args.dry_run:
+        return dry_run_worker(args, world, rank)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    set_default_device(device)
+    dist = None
+    force_dist = os.environ.get('NNL_BENCH_FORCE_DIST') == '1'       # exercise the RCCL path on a 1-GPU box (world_size 1)
+    ranks_seen = 1
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+    clock = Clock(dist, device)
+    seed = 1234 + 1 + 1000 * rank
+
+    # ---- headline: weak scaling, args.bs images per GPU ----
+    wl = resnet34_workload(device, args.bs, seed, world, args.sz)
+    dt = clock.timed(wl.step, args.warmup, args.steps)
+    ms = dt / args.steps * 1e3
+    last_loss = wl.loss
+    n_prof = min(args.steps, 10)
+    prof = profile_kinds(wl, n_prof)
+    roofline = mfma_roofline(prof, n_prof, kernel='igemm_taps_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: '
+                                                  'fwd, dgrad, wgrad; incl. their slab reduces)')
+    roofline['conv_ms_per_step'] = roofline['kernel_ms_per_step']
+    roofline['traffic'], src = committed_traffic(args.bs, args.sz, world)
+    if src:
+        roofline['traffic_source'] = src
+    out = {
+        'metric': 'ResNet-34 224x224 training throughput (Learner.train1minibatch, fwd+loss+bwd+optimizer)',
+        'value': round(args.bs * world * args.steps / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'ranks_seen': ranks_seen,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'DogsCats ResNet-34 classifier, 224x224, bs=%d per GPU, SGD momentum 0.9, fp32' % args.bs,
+                   'global_batch': args.bs * world, 'image_size': args.sz, 'parallelism': 'dp%d' % world, 'last_loss': last_loss},
+        'roofline': roofline,
+    }
+    if wl.learner.grad_sync is not None and dist is not None:
+        out['dp'] = dp_diagnostics(wl, clock, dist, args.steps, ms)
+    del wl
+    torch.cuda.empty_cache()
+
+    # ---- strong scaling: GLOBAL batch args.bs (north-star: >= 6.5x at 8 GPUs) ----
+    if world > 1:
+        per = max(args.bs // world, 1)
+        strong = {'global_batch': per * world, 'per_gpu_batch': per}
+        for tag, sync_bn in (('local_bn', False), ('sync_bn', True)):
+            w2 = resnet34_workload(device, per, seed, world, args.sz, sync_bn=sync_bn)
+            d2 = clock.timed(w2.step, args.warmup, args.steps)
+            strong[tag] = {'ms_per_step': round(d2 / args.steps * 1e3, 3), 'value': round(per * world * args.steps / d2, 2)}
+            del w2
+            torch.cuda.empty_cache()
+        strong['note'] = ('local_bn: per-replica BatchNorm statistics (standard DDP); sync_bn: global-batch statistics = the single-GPU '
+                          "reference's numerics on the same global minibatch (SURVEY.md §8e)")
+        out['strong'] = strong
+    elif not args.no_sweep:
+        # one GPU: the compute-side ceiling of strong scaling — the per-GPU step at 64/N images
+        proxy = {'t64_ms': round(ms, 3)}
+        for bs in (32, 16, 8):
+            w2 = resnet34_workload(device, bs, seed, 1, args.sz)
+            d2 = clock.timed(w2.step, max(args.warmup, 3), args.steps)
+            m2 = d2 / args.steps * 1e3
+            proxy['bs%d' % bs] = {'ms_per_step': round(m2, 3), 'images_per_s': round(bs * args.steps / d2, 1),
+                                  't64_over_t': round(ms / m2, 2), 'ideal': 64 // bs}
+            del w2
+            torch.cuda.empty_cache()
+        proxy['note'] = 't64_over_t at bs=64/N bounds the strong-scaling speed-up at N GPUs before any communication (target >= 6.5 at N=8)'
+        out['strong_scaling_proxy'] = proxy
+
+    # ---- the other four BASELINE configs ----
+    cpu = (not args.no_cpu_baseline) and world == 1 and rank == 0
+    if args.configs != 'none':
+        names = ['collab', 'tabular', 'lm', 'retinanet'] if args.configs == 'all' else args.configs.split(',')
+        out['configs'] = {}
+        for name in names:
+            k = {'collab': max(args.steps, 50), 'tabular': max(args.steps, 30), 'lm': min(args.steps, 10), 'retinanet': min(args.steps, 5)}[name]
+            out['configs'][name] = run_config(name, device, world, rank, clock, k, 3, cpu)
+    if cpu:
+        out['cpu_baseline'] = cpu_baseline_resnet(args.bs, args.sz)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -88,116 +699,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--bs', type=int, default=64, help='per-GPU batch (weak scaling) or global batch (--scaling strong)')
+    ap.add_argument('--bs', type=int, default=64, help='images per GPU of the headline (weak scaling); also the GLOBAL batch of the strong-scaling leg')
     ap.add_argument('--sz', type=int, default=224)
-    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
+    ap.add_argument('--configs', default='all', help="'all', 'none' or a comma list of collab,tabular,lm,retinanet")
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the 1-GPU bs 8/16/32 strong-scaling proxy')
+    ap.add_argument('--dry-run', action='store_true', help='CPU + gloo rehearsal of the launch / timing / JSON protocol (no HIP path)')
     args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the HIP hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    dist = None
-    force_dist = os.environ.get('NNL_BENCH_FORCE_DIST') == '1'       # exercise the RCCL path on a 1-GPU box (world_size 1)
-    if world > 1 or force_dist:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-
-    per_gpu_bs = args.bs if args.scaling == 'weak' else max(args.bs // world, 1)
-    learner, data = build_learner(device, per_gpu_bs, args.sz, 1234 + 1 + 1000 * rank)
-    if world > 1 or force_dist:
-        learner.distribute()
-    learner.model.train()
-    lr = [1e-3, 3e-3, 1e-2]
-
-    def step(i):
-        x, y = data.batches[i % len(data.batches)]
-        return learner.train1minibatch(x, y, lr)
-
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- roofline leg: same steps again with per-launch HIP events on the launch stream ----
-    from neuralnetworklibrary_amd import _lib
-    _lib.prof_enable(True)
-    n_prof = min(args.steps, 10)
-    for i in range(n_prof):
-        step(i)
-    torch.cuda.synchronize()
-    _lib.prof_enable(False)
-    prof = _lib.prof_collect()
-    conv_ms = sum(prof[k]['ms'] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
-    conv_flop = sum(prof[k]['work'] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
-    conv_launches = sum(prof[k]['launches'] for k in ('conv_fwd', 'conv_dgrad', 'conv_wgrad'))
-    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # HBM-side bytes per launch of the dominant kernel come from separate rocprofv3 --pmc passes of THIS command
-    # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); the committed summary is profiles/r1_traffic.json
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
-            traffic = round(json.load(f)['traffic_bytes_per_launch'])
-    except Exception:
-        pass
-    roofline = {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
-                'kernel': 'igemm_taps_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: fwd, dgrad, wgrad; incl. their slab reduces)',
-                'launches_per_step': conv_launches / max(n_prof, 1),
-                'avg_launch_ms': conv_ms / max(conv_launches, 1),
-                'flop_per_launch': conv_flop / max(conv_launches, 1),
-                'conv_ms_per_step': conv_ms / max(n_prof, 1),
-                # per C-entry-point family: algorithmic FLOPs (conv / gemm / lstm) or algorithmic BYTES (the HBM-bound kinds)
-                'by_kind': {k: {'ms_per_step': round(v['ms'] / max(n_prof, 1), 3),
-                                ('tflops' if k in FLOP_KINDS else 'tbytes_per_s'):
-                                    round(v['work'] / (v['ms'] * 1e-3) / 1e12, 2) if v['ms'] > 0 else None}
-                            for k, v in prof.items() if v['launches']}}
-
-    if rank == 0:
-        global_bs = per_gpu_bs * world
-        ms = dt / args.steps * 1e3
-        out = {
-            'metric': 'ResNet-34 224x224 training throughput (Learner.train1minibatch, fwd+loss+bwd+optimizer)',
-            'value': round(global_bs * args.steps / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': args.scaling,
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'DogsCats ResNet-34 classifier, 224x224, bs=%d per GPU, SGD momentum 0.9, fp32' % per_gpu_bs,
-                       'global_batch': global_bs, 'image_size': args.sz, 'parallelism': 'dp%d' % world,
-                       'last_loss': loss},
-            'roofline': roofline,
-        }
-        if learner.grad_sync is not None:                # data parallel: how the gradients reached the all-reduce buckets
-            gs = learner.grad_sync
-            out['config']['grad_buckets'] = len(gs.buckets)
-            out['config']['grads_written_in_place'] = '%d of %d tensors per step' % (
-                gs.direct_writes // max(gs.steps, 1), sum(len(b.params) for b in gs.buckets))
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(per_gpu_bs, args.sz)
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))                # BEFORE any GPU call in this process
+    worker(args)
 
 
 if __name__ == '__main__':

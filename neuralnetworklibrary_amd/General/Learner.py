@@ -195,6 +195,20 @@ class Learner(object):
         synthetic benchmarks): it skips the per-step batch-size agreement described at `_dp_batch_sizes`."""
         from .. import dist as nnl_dist
         self._dp_equal_shards = bool(equal_shards)
+        d = _dist()
+        if d is not None and d.get_world_size() > 1:
+            # replicas start identical: rank 0's parameters and buffers (BN running statistics) everywhere
+            with torch.no_grad():
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    t = t.data
+                    if t.is_contiguous():
+                        d.broadcast(t, 0)
+                    elif t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+                        d.broadcast(t.permute(0, 2, 3, 1), 0)          # conv filters are stored KRSC: a dense view
+                    else:
+                        c = t.contiguous()
+                        d.broadcast(c, 0)
+                        t.copy_(c)
         self.grad_sync = nnl_dist.GradSync(self.model, bucket_mb=bucket_mb)
         self.optimizer.attach_grad_sync(self.grad_sync)
         if sync_bn:
