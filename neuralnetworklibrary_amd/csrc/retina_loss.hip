@@ -1,11 +1,18 @@
 // K6 — fused RetinaNet detection loss: anchor/object matching + focal loss + smooth-L1 box loss for a whole batch,
-// forward in one launch (+ a tiny fixed-order finalize), backward in one launch, no host synchronisation.
+// forward in ONE launch (the last block to finish reduces the per-block partial sums in a fixed order), backward in one
+// launch, no host synchronisation.
 // Replaces SSD_loss.__call__ -> ssd1 -> match_anchors_objects / focal_loss_retina / smoothL1_loss_retina
 // (Applications/Vision.py:1474-1511, 1513-1530, 1532-1566, 1568-1605, 1620-1644) whose reference form is a Python
 // loop over images (:1636), a Python loop over positive anchors (:1593) and two .nonzero() syncs per image.
 //
 // HBM-bound: per (image, anchor) 16 B anchor + 16 B reg + 4K B clas read, 4 B state written (fwd); the same read
-// again + 16 + 4K B gradient written (bwd): 224 B per anchor at K = 20.
+// again + 16 + 4K B gradient written (bwd): 224 B per anchor at K = 20.  Layout of the work: a block owns a
+// chunk of 256 consecutive anchors of one image.  Phase 1, one lane per anchor: 16-B anchor / state / reg / dreg accesses,
+// consecutive lanes on consecutive addresses; the IoU loop runs over the image's objects in LDS; the anchor's target class goes
+// to LDS.  Phase 2, the chunk's clas / dclas rows as ONE flat stream of 16-B pieces (K = 20: five per anchor), consecutive
+// lanes on consecutive pieces — the class index and the anchor of an element follow from its position, the target class
+// comes from LDS.  (The first version walked each anchor's K classes from one lane: an 80-B lane stride, every wave
+// instruction touched 64 cache lines.)  reg is read for positive anchors only.
 //
 // Per-image semantics restated exactly (same operation order, single IEEE ops, no FMA contraction => the match
 // thresholds see bit-identical IoU values):
@@ -18,7 +25,7 @@
 
 namespace {
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;    // threads per block = anchors per chunk
 constexpr int kMaxObj = 128;   // objects per image held in LDS
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -48,38 +55,78 @@ __device__ __forceinline__ Encoded encode_box(const float4 a, const float4 o) {
   return e;
 }
 
-__device__ __forceinline__ float powg(float x, float gamma) { return gamma == 2.f ? x * x : powf(x, gamma); }
+template <bool G2>
+__device__ __forceinline__ float powg(float x, float gamma) { return G2 ? x * x : powf(x, gamma); }
+template <bool G2>
+__device__ __forceinline__ float powg1(float x, float gamma) { return G2 ? x : powf(x, gamma - 1.f); }   // x^(gamma-1)
 
-// grid: (blocks_per_image, bs).  part[(img*gridDim.x + blk)*3 + {0,1,2}] = {focal sum, smoothL1 sum, #pos}
+// The valid objects of image `img` (Vision.py:1637-1638: rows padded with -1 are dropped), compacted in order into LDS by the
+// first two waves: one load per lane, ballot + prefix count instead of a serial loop of dependent loads.  Returns their count.
+__device__ __forceinline__ int load_objects(const float* __restrict__ boxes, const int64_t* __restrict__ cats, int img, int M,
+                                            float4* s_box, float* s_area, int* s_cat, int* s_cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t c = -1;
+  float4 b = {0.f, 0.f, 0.f, 0.f};
+  if (tid < M) {                                    // M <= kMaxObj = 128: waves 0 and 1
+    c = cats[(long)img * M + tid];
+    b = reinterpret_cast<const float4*>(boxes)[(long)img * M + tid];
+  }
+  const bool keep = c >= 0;
+  const unsigned long long mask = __ballot(keep);
+  const int before = __popcll(mask & ((1ull << lane) - 1ull));
+  if (lane == 0 && wave < 2) s_cnt[wave] = __popcll(mask);
+  __syncthreads();
+  if (keep) {
+    const int pos = before + (wave == 1 ? s_cnt[0] : 0);
+    s_box[pos] = b;
+    if (s_area) s_area[pos] = (b.z - b.x) * (b.w - b.y);
+    s_cat[pos] = (int)c;
+  }
+  __syncthreads();
+  return s_cnt[0] + s_cnt[1];
+}
+
+// forward focal term of one class probability (Vision.py:1525-1528 with t in {0,1}): pt = p (t=1) or 1-p (t=0);
+// w = wa*(1-pt)^gamma — for t=0 the reference evaluates 1-(1-p) in fp32, which is not bitwise p: keep that form
+template <bool G2>
+__device__ __forceinline__ float focal_term(float x, bool is_target, float alpha, float gamma) {
+  const float p = fminf(fmaxf(x, 1e-4f), 1.0f - 1e-4f);
+  const float q = 1.f - p;
+  return is_target ? -(alpha * powg<G2>(q, gamma)) * logf(p) : -((1.f - alpha) * powg<G2>(1.f - q, gamma)) * logf(q);
+}
+
+template <bool G2>
+__device__ __forceinline__ float focal_grad(float raw, bool is_target, float alpha, float gamma) {
+  if (!(raw >= 1e-4f && raw <= 1.0f - 1e-4f)) return 0.f;      // clamp passes gradient only inside its range
+  const float p = raw;
+  if (is_target) {                                              // L = -alpha (1-p)^g log p
+    const float q = 1.f - p;
+    return alpha * (gamma * powg1<G2>(q, gamma) * logf(p) - powg<G2>(q, gamma) / p);
+  }
+  return (1.f - alpha) * (-gamma * powg1<G2>(p, gamma) * logf(1.f - p) + powg<G2>(p, gamma) / (1.f - p));   // L = -(1-alpha) p^g log(1-p)
+}
+
+// grid: (chunks per image, bs).  part[(img*gridDim.x + chunk)*3 + {0,1,2}] = {focal sum, smoothL1 sum, #pos}; the block that
+// takes the last ticket reduces them per image in a fixed order and writes out[3] / npos[bs].  *ticket is 0 at rest.
+template <bool G2>
 __global__ __launch_bounds__(kBlock) void retina_fwd_kernel(
     const float* __restrict__ anchors, const float* __restrict__ reg, const float* __restrict__ clas,
     const float* __restrict__ boxes, const int64_t* __restrict__ cats, int32_t* __restrict__ state,
-    float* __restrict__ part, int A, int K, int M, float alpha, float gamma) {
+    float* __restrict__ part, int* __restrict__ ticket, float* __restrict__ out, float* __restrict__ npos_out,
+    int A, int K, int M, float alpha, float gamma, float beta) {
   __shared__ float4 s_box[kMaxObj];
   __shared__ float s_area[kMaxObj];
   __shared__ int s_cat[kMaxObj];
-  __shared__ int s_m;
+  __shared__ int s_cnt[2];
+  __shared__ int s_t[kBlock];           // per anchor of the chunk: target class (>= 0), -1 negative, -2 ignored / out of range
   __shared__ float red[4];
-  const int img = blockIdx.y;
-  // compact the valid objects of this image (Vision.py:1637-1638: rows padded with -1 are dropped), keeping order
-  if (threadIdx.x == 0) {
-    int m = 0;
-    for (int j = 0; j < M && m < kMaxObj; ++j) {
-      const int64_t c = cats[(long)img * M + j];
-      if (c >= 0) {
-        const float4 b = reinterpret_cast<const float4*>(boxes)[(long)img * M + j];
-        s_box[m] = b;
-        s_area[m] = (b.z - b.x) * (b.w - b.y);
-        s_cat[m] = (int)c;
-        ++m;
-      }
-    }
-    s_m = m;
-  }
-  __syncthreads();
-  const int m = s_m;
-  float focal = 0.f, sl1 = 0.f, npos = 0.f;
-  for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
+  __shared__ int s_last;
+  const int img = blockIdx.y, tid = threadIdx.x;
+  const int m = load_objects(boxes, cats, img, M, s_box, s_area, s_cat, s_cnt);
+  const int a0 = blockIdx.x * kBlock, a = a0 + tid;
+  float focal = 0.f, sl1 = 0.f, np = 0.f;
+  int tcls = -2;
+  if (a < A) {
     const float4 an = reinterpret_cast<const float4*>(anchors)[a];
     const float area_a = (an.z - an.x) * (an.w - an.y);
     float best = -1.f;
@@ -98,19 +145,9 @@ __global__ __launch_bounds__(kBlock) void retina_fwd_kernel(
     else if (best < 0.4f) st = -1;
     else st = -2;
     state[(long)img * A + a] = st;
-    if (st == -2) continue;
-    const int tcls = st >= 0 ? s_cat[st] : -1;
-    const float* __restrict__ cp = clas + ((long)img * A + a) * K;
-    for (int k = 0; k < K; ++k) {
-      const float p = fminf(fmaxf(cp[k], 1e-4f), 1.0f - 1e-4f);
-      // Vision.py:1525-1528 with t in {0,1}: pt = p (t=1) or 1-p (t=0); w = wa*(1-pt)^gamma — for t=0 the reference
-      // evaluates 1-(1-p) in fp32, which is not bitwise p: keep that form
-      const float q = 1.f - p;
-      if (k == tcls) focal += -(alpha * powg(q, gamma)) * logf(p);
-      else focal += -((1.f - alpha) * powg(1.f - q, gamma)) * logf(q);
-    }
+    tcls = st >= 0 ? s_cat[st] : st;
     if (st >= 0) {
-      npos += 1.f;
+      np = 1.f;
       const Encoded e = encode_box(an, s_box[st]);
       const float4 r = reinterpret_cast<const float4*>(reg)[(long)img * A + a];
       const float rr[4] = {r.x, r.y, r.z, r.w};
@@ -121,37 +158,85 @@ __global__ __launch_bounds__(kBlock) void retina_fwd_kernel(
       }
     }
   }
+  s_t[tid] = tcls;
+  __syncthreads();
+  // the chunk's class probabilities as one flat stream
+  const int n_anch = min(kBlock, A - a0);
+  const float* __restrict__ cp = clas + ((long)img * A + a0) * K;
+  const float inv_k = 1.f / (float)K;
+  if ((K & 3) == 0) {
+    const int nv = n_anch * K / 4;
+    for (int f = tid; f < nv; f += kBlock) {
+      const float4 v = reinterpret_cast<const float4*>(cp)[f];
+      const int e = 4 * f;
+      const int an = (int)(((float)e + 0.5f) * inv_k);          // e / K (exact: (e + .5) / K is >= .5 / K away from an integer)
+      const int k0 = e - an * K;
+      const int t = s_t[an];
+      if (t != -2) {
+        focal += focal_term<G2>(v.x, k0 == t, alpha, gamma);
+        focal += focal_term<G2>(v.y, k0 + 1 == t, alpha, gamma);
+        focal += focal_term<G2>(v.z, k0 + 2 == t, alpha, gamma);
+        focal += focal_term<G2>(v.w, k0 + 3 == t, alpha, gamma);
+      }
+    }
+  } else {
+    const int ne = n_anch * K;
+    for (int e = tid; e < ne; e += kBlock) {
+      const int an = (int)(((float)e + 0.5f) * inv_k);
+      const int t = s_t[an];
+      if (t != -2) focal += focal_term<G2>(cp[e], e - an * K == t, alpha, gamma);
+    }
+  }
   focal = block_sum(focal, red);
   sl1 = block_sum(sl1, red);
-  npos = block_sum(npos, red);
-  if (threadIdx.x == 0) {
-    float* o = part + ((long)img * gridDim.x + blockIdx.x) * 3;
-    o[0] = focal; o[1] = sl1; o[2] = npos;
+  np = block_sum(np, red);
+  const int nblk = gridDim.x, bs = gridDim.y;
+  if (tid == 0) {
+    // hand-over WITHOUT cache-wide fences (an acquire / release at agent scope writes back and invalidates the XCD's whole L2
+    // once per block: measured 111 us instead of ~25): the three partial sums go out as agent-scope (write-through) stores, are
+    // drained (vmcnt 0) before the ticket is taken, and the last block reads them with agent-scope loads
+    float* o = part + ((long)img * nblk + blockIdx.x) * 3;
+    __hip_atomic_store(o + 0, focal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 1, sl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 2, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == nblk * bs - 1;
   }
-}
-
-// out[0] = total loss, out[1] = reg loss, out[2] = clas loss (batch means); npos[img] kept for backward
-__global__ void retina_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ npos,
-                                       int bs, int nblk, float beta) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  float reg_sum = 0.f, clas_sum = 0.f;
-  for (int i = 0; i < bs; ++i) {
+  __syncthreads();
+  if (!s_last) return;
+  // ---- finalize (one block): wave w reduces images w, w+4, ...; lane l adds partials l, l+64, ... then a fixed shuffle tree.
+  // The order depends only on (bs, nblk), never on which block came last.
+  const int lane = tid & 63, wave = tid >> 6;
+  float clas_sum = 0.f, reg_sum = 0.f;
+  for (int i = wave; i < bs; i += 4) {
     float f = 0.f, s = 0.f, n = 0.f;
-    for (int b = 0; b < nblk; ++b) {
-      const float* p = part + ((long)i * nblk + b) * 3;
-      f += p[0]; s += p[1]; n += p[2];
+    for (int b = lane; b < nblk; b += 64) {
+      float* p = part + ((long)i * nblk + b) * 3;
+      f += __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      n += __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    npos[i] = n;
+    f = nnl_wave_sum(f); s = nnl_wave_sum(s); n = nnl_wave_sum(n);
+    if (lane == 0) npos_out[i] = n;
     clas_sum += f / fmaxf(n, 1.f);
     reg_sum += n > 0.f ? s / (n * 4.f) : 0.f;
   }
-  const float r = reg_sum / bs, c = clas_sum / bs;
-  out[1] = r;
-  out[2] = c;
-  out[0] = (1.f - beta) * r + beta * c;
+  __shared__ float fin[8];
+  if (lane == 0) { fin[wave] = clas_sum; fin[4 + wave] = reg_sum; }
+  __syncthreads();
+  if (tid == 0) {
+    const float c = ((fin[0] + fin[1]) + (fin[2] + fin[3])) / bs;
+    const float r = ((fin[4] + fin[5]) + (fin[6] + fin[7])) / bs;
+    out[1] = r;
+    out[2] = c;
+    out[0] = (1.f - beta) * r + beta * c;
+    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero at rest for the next launch on this stream
+  }
 }
 
-// gradients wrt reg [bs,A,4] and clas [bs,A,K]; gscale = upstream d(loss) (device scalar pointer)
+// gradients wrt reg [bs,A,4] and clas [bs,A,K]; gup = upstream d(loss) (device scalar pointer)
+template <bool G2>
 __global__ __launch_bounds__(kBlock) void retina_bwd_kernel(
     const float* __restrict__ anchors, const float* __restrict__ reg, const float* __restrict__ clas,
     const float* __restrict__ boxes, const int64_t* __restrict__ cats, const int32_t* __restrict__ state,
@@ -159,45 +244,20 @@ __global__ __launch_bounds__(kBlock) void retina_bwd_kernel(
     int A, int K, int M, int bs, float alpha, float gamma, float beta) {
   __shared__ float4 s_box[kMaxObj];
   __shared__ int s_cat[kMaxObj];
-  const int img = blockIdx.y;
-  if (threadIdx.x == 0) {
-    int m = 0;
-    for (int j = 0; j < M && m < kMaxObj; ++j) {
-      const int64_t c = cats[(long)img * M + j];
-      if (c >= 0) { s_box[m] = reinterpret_cast<const float4*>(boxes)[(long)img * M + j]; s_cat[m] = (int)c; ++m; }
-    }
-  }
-  __syncthreads();
+  __shared__ int s_cnt[2];
+  __shared__ int s_t[kBlock];
+  const int img = blockIdx.y, tid = threadIdx.x;
+  load_objects(boxes, cats, img, M, s_box, nullptr, s_cat, s_cnt);
   const float g = gup[0];
   const float n = npos[img];
   const float gc = g * beta / (bs * fmaxf(n, 1.f));
   const float gr = n > 0.f ? g * (1.f - beta) / (bs * n * 4.f) : 0.f;
-  for (int a = blockIdx.x * kBlock + threadIdx.x; a < A; a += gridDim.x * kBlock) {
+  const int a0 = blockIdx.x * kBlock, a = a0 + tid;
+  int tcls = -2;
+  if (a < A) {
     const long ia = (long)img * A + a;
     const int st = state[ia];
-    const float* __restrict__ cp = clas + ia * K;
-    float* __restrict__ dp = dclas + ia * K;
-    if (st == -2) {
-      for (int k = 0; k < K; ++k) dp[k] = 0.f;
-    } else {
-      const int tcls = st >= 0 ? s_cat[st] : -1;
-      for (int k = 0; k < K; ++k) {
-        const float raw = cp[k];
-        float d = 0.f;
-        if (raw >= 1e-4f && raw <= 1.0f - 1e-4f) {       // clamp passes gradient only inside its range
-          const float p = raw;
-          if (k == tcls) {
-            // L = -alpha (1-p)^g log p
-            const float q = 1.f - p;
-            d = alpha * (gamma * powg(q, gamma - 1.f) * logf(p) - powg(q, gamma) / p);
-          } else {
-            // L = -(1-alpha) p^g log(1-p)
-            d = (1.f - alpha) * (-gamma * powg(p, gamma - 1.f) * logf(1.f - p) + powg(p, gamma) / (1.f - p));
-          }
-        }
-        dp[k] = d * gc;
-      }
-    }
+    tcls = st >= 0 ? s_cat[st] : st;
     float4 dr = {0.f, 0.f, 0.f, 0.f};
     if (st >= 0) {
       const float4 an = reinterpret_cast<const float4*>(anchors)[a];
@@ -217,38 +277,66 @@ __global__ __launch_bounds__(kBlock) void retina_bwd_kernel(
     }
     reinterpret_cast<float4*>(dreg)[ia] = dr;
   }
+  s_t[tid] = tcls;
+  __syncthreads();
+  const int n_anch = min(kBlock, A - a0);
+  const float* __restrict__ cp = clas + ((long)img * A + a0) * K;
+  float* __restrict__ dp = dclas + ((long)img * A + a0) * K;
+  const float inv_k = 1.f / (float)K;
+  if ((K & 3) == 0) {
+    const int nv = n_anch * K / 4;
+    for (int f = tid; f < nv; f += kBlock) {
+      const int e = 4 * f;
+      const int an = (int)(((float)e + 0.5f) * inv_k);
+      const int k0 = e - an * K;
+      const int t = s_t[an];
+      float4 d = {0.f, 0.f, 0.f, 0.f};
+      if (t != -2) {
+        const float4 v = reinterpret_cast<const float4*>(cp)[f];
+        d.x = focal_grad<G2>(v.x, k0 == t, alpha, gamma) * gc;
+        d.y = focal_grad<G2>(v.y, k0 + 1 == t, alpha, gamma) * gc;
+        d.z = focal_grad<G2>(v.z, k0 + 2 == t, alpha, gamma) * gc;
+        d.w = focal_grad<G2>(v.w, k0 + 3 == t, alpha, gamma) * gc;
+      }
+      reinterpret_cast<float4*>(dp)[f] = d;
+    }
+  } else {
+    const int ne = n_anch * K;
+    for (int e = tid; e < ne; e += kBlock) {
+      const int an = (int)(((float)e + 0.5f) * inv_k);
+      const int t = s_t[an];
+      dp[e] = t != -2 ? focal_grad<G2>(cp[e], e - an * K == t, alpha, gamma) * gc : 0.f;
+    }
+  }
 }
 
-int blocks_per_image(int A) {
-  long b = nnl_cdiv(A, kBlock);
-  if (b > 256) b = 256;
-  if (b < 1) b = 1;
-  return (int)b;
-}
+int chunks_per_image(long A) { return (int)nnl_cdiv(A, kBlock); }
 
 }  // namespace
 
 extern "C" size_t nnl_retina_loss_workspace_bytes(int64_t bs, int64_t A) {
   if (bs <= 0 || A <= 0) return 0;
-  return (size_t)(bs * blocks_per_image((int)A) * 3) * sizeof(float);
+  return (size_t)(bs * chunks_per_image(A) * 3) * sizeof(float);
 }
 
 extern "C" int nnl_retina_loss_fwd(const float* anchors, const float* reg, const float* clas, const float* boxes,
                                    const int64_t* cats, int32_t* state, float* npos, float* out, int64_t bs, int64_t A,
                                    int64_t K, int64_t M, float beta, float alpha, float gamma, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
-  NNL_CHECK_ARG(bs > 0 && A > 0 && K > 0 && M >= 0 && A < (1L << 30) && bs < 65536, "retina_loss_fwd: bad sizes");
+                                   size_t workspace_bytes, int32_t* ticket, void* stream) {
+  NNL_CHECK_ARG(bs > 0 && A > 0 && K > 0 && M >= 0 && A < (1L << 30) && bs < 65536 && K <= 4096, "retina_loss_fwd: bad sizes");
   NNL_CHECK_ARG(M <= kMaxObj, "retina_loss_fwd: at most %d objects per image (got %ld)", kMaxObj, (long)M);
-  NNL_CHECK_ARG(anchors && reg && clas && state && npos && out && (M == 0 || (boxes && cats)), "retina_loss_fwd: null pointer");
+  NNL_CHECK_ARG(anchors && reg && clas && state && npos && out && ticket && (M == 0 || (boxes && cats)), "retina_loss_fwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_retina_loss_workspace_bytes(bs, A))
     return nnl_set_error(NNL_ERR_WORKSPACE, "retina_loss_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  const int nblk = blocks_per_image((int)A);
+  const dim3 grid(chunks_per_image(A), (unsigned)bs);
   NnlProfScope prof(NNL_PROF_RETINA_LOSS, s, (double)bs * A * (16 + 16 + 4.0 * K + 4));
-  hipLaunchKernelGGL(retina_fwd_kernel, dim3(nblk, (unsigned)bs), dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state,
-                     (float*)workspace, (int)A, (int)K, (int)M, alpha, gamma);
-  NNL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(retina_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, out, npos, (int)bs, nblk, beta);
+  if (gamma == 2.f)
+    hipLaunchKernelGGL(retina_fwd_kernel<true>, grid, dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state, (float*)workspace,
+                       (int*)ticket, out, npos, (int)A, (int)K, (int)M, alpha, gamma, beta);
+  else
+    hipLaunchKernelGGL(retina_fwd_kernel<false>, grid, dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state, (float*)workspace,
+                       (int*)ticket, out, npos, (int)A, (int)K, (int)M, alpha, gamma, beta);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -257,12 +345,17 @@ extern "C" int nnl_retina_loss_bwd(const float* anchors, const float* reg, const
                                    const int64_t* cats, const int32_t* state, const float* npos, const float* grad_out,
                                    float* dreg, float* dclas, int64_t bs, int64_t A, int64_t K, int64_t M, float beta,
                                    float alpha, float gamma, void* stream) {
-  NNL_CHECK_ARG(bs > 0 && A > 0 && K > 0 && M >= 0 && M <= kMaxObj, "retina_loss_bwd: bad sizes");
+  NNL_CHECK_ARG(bs > 0 && A > 0 && K > 0 && M >= 0 && M <= kMaxObj && bs < 65536 && K <= 4096, "retina_loss_bwd: bad sizes");
   NNL_CHECK_ARG(anchors && reg && clas && state && npos && grad_out && dreg && dclas, "retina_loss_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(chunks_per_image(A), (unsigned)bs);
   NnlProfScope prof(NNL_PROF_RETINA_LOSS, s, (double)bs * A * (16 + 32 + 8.0 * K + 4));
-  hipLaunchKernelGGL(retina_bwd_kernel, dim3(blocks_per_image((int)A), (unsigned)bs), dim3(kBlock), 0, s, anchors, reg, clas,
-                     boxes, cats, state, npos, grad_out, dreg, dclas, (int)A, (int)K, (int)M, (int)bs, alpha, gamma, beta);
+  if (gamma == 2.f)
+    hipLaunchKernelGGL(retina_bwd_kernel<true>, grid, dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state, npos, grad_out, dreg,
+                       dclas, (int)A, (int)K, (int)M, (int)bs, alpha, gamma, beta);
+  else
+    hipLaunchKernelGGL(retina_bwd_kernel<false>, grid, dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state, npos, grad_out, dreg,
+                       dclas, (int)A, (int)K, (int)M, (int)bs, alpha, gamma, beta);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

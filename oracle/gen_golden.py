@@ -188,6 +188,41 @@ def g6_resnet34():
     save('g6_resnet34', **out)
 
 
+def g13_resnet34_curve():
+    """G13: 20 consecutive `Learner.train1minibatch` steps of the REFERENCE at BASELINE configs[1]'s own size — ResNet-34 body +
+    default head (dropout 0), 224x224, bs 64, SGD momentum 0.9, lr [1e-3, 3e-3, 1e-2], wd 1e-4, BatchNorm in training mode — in
+    fp32 and, with the same modules cast to fp64, in fp64: per-step losses, post-run parameter checksums.  Four synthetic batches
+    (synth_input tags 130..133, labels (7 i + b) mod 2) are cycled.  ~10 min on 8 cores (fp64 convolutions)."""
+    RN = R['Applications.VisionModels.retinanet']
+    V = R['Applications.Vision']
+    N, S, STEPS = 64, 224, 20
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
+
+    xs = [synth.synth_input((N, 3, S, S), 130 + b) for b in range(4)]
+    ys = [(torch.arange(N) * 7 + b) % 2 for b in range(4)]
+    out = {'N': N, 'S': S, 'steps': STEPS, 'lr': np.array([1e-3, 3e-3, 1e-2]), 'wd': 1e-4}
+    for tag, dtype in [('f32', torch.float32), ('f64', torch.float64)]:
+        arch = RN.RetinaNet(2, RN.BasicBlock, [3, 4, 6, 3])
+        net = V.ImageClassificationNet(D, arch, head=[[512], [0., 0.]], cutpoint=8, splits=[6])
+        synth.fill_module_(net, seed=5)
+        net = net.to(dtype).train()
+        d = D(); d.train_dl = [(xs[0], ys[0])]; d.val_dl = d.train_dl
+        learner = Learner('/tmp/nnl_golden_g13', d, net, optimizer='SGD_Mom')
+        learner.init_optimizer(wd=1e-4)
+        losses = []
+        for i in range(STEPS):
+            losses.append(learner.train1minibatch(xs[i % 4].to(dtype), ys[i % 4], [1e-3, 3e-3, 1e-2]))
+            print(tag, i, losses[-1], flush=True)
+        out['losses.' + tag] = np.array(losses, dtype=np.float64)
+        out['after.abs_sums.' + tag] = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+        out['after.sums.' + tag] = np.array([p.double().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+        if tag == 'f32':
+            out['param_names'] = np.array([n for n, _ in net.named_parameters()])
+    save('g13_resnet34_curve', **out)
+
+
 def g3_tabular():
     """G2+G3: EmbeddingDrop renorm (weight before/after, output) and StructuredDataNet (cards [20,5,4,13], n_cont 3, fc
     [32,16,1], range [5,12], dropout 0): forward, MSE loss, all gradients, then 3 Learner.train1minibatch steps (Adam,
@@ -670,7 +705,7 @@ def g4_fcnet_and_g10_fit_curves():
     save('g4_g10_fcnet_fit', **out)
 
 
-GROUPS = {'g4': g4_fcnet_and_g10_fit_curves, 'g12': g12_objectdetectionnet, 'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34}
+GROUPS = {'g4': g4_fcnet_and_g10_fit_curves, 'g12': g12_objectdetectionnet, 'g11': g11_bbox_inference, 'g1': g1_collab, 'g9': g9_host_logic, 'g7': g7_text, 'g8': g8_detection, 'g3': g3_tabular, 'g5': g5_blocks, 'g6': g6_resnet34, 'g13': g13_resnet34_curve}
 
 if __name__ == '__main__':
     names = sys.argv[1:] or sorted(GROUPS)

@@ -121,11 +121,27 @@ def test_full_size_vs_oracle():
     assert_close(cg.grad, cc.grad, 1e-4, 1e-9, 'dclas')
 
 
-def assert_within_reference_gap(got, g, key, msg, slack=3.0, floor=1e-3):
+def assert_within_reference_gap(got, g, key, msg, slack=3.0, floor=1e-3, normwise=False, host32=None):
     """|got - f64| <= slack * gap + floor * |f64| elementwise, gap = the reference's own |fp32 - fp64| (never below its 95th
-    percentile over the tensor: a single fp32 run is one noisy sample of its error)."""
+    percentile over the tensor: a single fp32 run is one noisy sample of its error).
+    normwise=True (gradient tensors): ||got - f64|| <= slack ||f32 - f64|| + floor ||f64|| over the whole tensor.  A gradient is
+    a discontinuous function of the weights (ReLU gates: an activation within rounding of zero gets the opposite gate in two
+    correct fp32 evaluations and moves every weight-gradient element it feeds), so single elements of two correct fp32 results
+    legitimately differ by more than 1e-3 of their own magnitude; the tensor as a whole may not.
+    host32: the same quantity from the CPU oracle in fp32 ON THIS HOST.  At G12's size (C5 is 2x2 pixels, P6 / P7 one pixel) one
+    gate decides ~1e-3 of every upstream gradient, and torch's own fp32 CPU run is not reproducible across hosts at that level:
+    measured on the GPU box, torch-CPU fp32 sits 5.4e-3 from the golden fp64 on fpn.P5_1.weight where the golden fp32 (made in
+    the build container: other ISA, other mkldnn blocking) sits 2.8e-6 — and the HIP result equals the box's torch-CPU fp32 to
+    2e-6.  The gap is therefore the larger of the two fp32 separations: "as far from fp64 as torch fp32 on this machine"."""
     r32, r64 = g[key + '.f32'], g[key + '.f64']
     got = got.detach().cpu().double().numpy().reshape(r64.shape)
+    if normwise:
+        err, gapn, ref = np.linalg.norm(got - r64), np.linalg.norm(r32 - r64), np.linalg.norm(r64)
+        if host32 is not None:
+            gapn = max(gapn, np.linalg.norm(host32.detach().cpu().double().numpy().reshape(r64.shape) - r64))
+        assert err <= slack * gapn + floor * ref, '%s: ||got-f64|| %.3e > %g x ||f32-f64|| %.3e + %g x ||f64|| %.3e' % (
+            msg, err, slack, gapn, floor, ref)
+        return
     gap = np.abs(r32 - r64)
     tol = slack * np.maximum(gap, np.quantile(gap, 0.95)) + floor * np.abs(r64) + 1e-12
     err = np.abs(got - r64)
@@ -176,10 +192,16 @@ def test_g12_objectdetectionnet_hip_vs_reference():
     x = synth.synth_input((N, 3, S, S), 12).to(DEV)
     B, Cc = T(g['boxes'], DEV), T(g['cats'], DEV)
     sd = dict(net.named_parameters())
+    from oracle import reference_math as RM, reference_nets as RN
+    onet = synth.fill_detection_net_(RN.ObjectDetectionNet(K))          # torch-CPU fp32 on this host: the second adjudicator
+    osd = dict(onet.named_parameters())
     for mode in ['train', 'eval']:
         net.train() if mode == 'train' else net.eval()
-        for p in net.parameters():
+        onet.train() if mode == 'train' else onet.eval()
+        for p in list(net.parameters()) + list(onet.parameters()):
             p.grad = None
+        oa, oreg, oclas = onet(x.cpu())
+        RM.ssd_loss(oa, oreg, oclas, B.cpu(), Cc.cpu(), 0.5, 0.25, 2.0)[0].backward()
         anchors, reg, clas = net(x)
         assert tuple(anchors.shape) == tuple(int(v) for v in g['anchors.shape'])
         lf = V.SSD_loss(0.5, 0.25, 2.0)
@@ -195,4 +217,48 @@ def test_g12_objectdetectionnet_hip_vs_reference():
         if mode == 'eval':
             for n in [str(s) for s in g['slice_names']]:
                 if 'eval.grad.%s.f32' % n in g:
-                    assert_within_reference_gap(sd[n].grad.reshape(-1)[:1024], g, 'eval.grad.' + n, 'eval grad ' + n, slack=slack)
+                    assert_within_reference_gap(sd[n].grad.reshape(-1)[:1024], g, 'eval.grad.' + n, 'eval grad ' + n, slack=slack,
+                                                normwise=True, host32=osd[n].grad.reshape(-1)[:1024])
+
+
+@pytest.mark.gpu
+def test_objectdetectionnet_full_baseline_size_vs_oracle_fp64():
+    """BASELINE configs[4] assembled at its own image size — ObjectDetectionNet(20): ResNet-50 Bottleneck body + FPN + shared
+    heads on five levels, 512 x 512 (49 104 anchors), 2 images, BatchNorm in training mode, SSD_loss(0.5, 0.25, 2) — one forward
+    + backward of the HIP path against the CPU oracle in fp32 AND fp64 on the same (well-conditioned, seeded) weights.
+    Activations elementwise and every parameter gradient in norm: |hip - f64| <= 3 |cpu32 - f64| + 1e-3 |f64|."""
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    from oracle import reference_math as RM, reference_nets as RN, synth
+    K, N, S = 20, 2, 512
+    x = synth.synth_input((N, 3, S, S), 77)
+    boxes = -np.ones((N, 4, 4), np.float32); cats = -np.ones((N, 4), np.int64)
+    boxes[0, :3] = [[30, 40, 200, 260], [250, 100, 420, 300], [100, 300, 180, 380]]; cats[0, :3] = [3, 17, 0]
+    boxes[1, :2] = [[60, 60, 460, 440], [10, 400, 90, 500]]; cats[1, :2] = [9, 19]
+    B, Cc = torch.from_numpy(boxes), torch.from_numpy(cats)
+    o32 = synth.fill_detection_net_(RN.ObjectDetectionNet(K), seed=3).train()
+    o64 = synth.fill_detection_net_(RN.ObjectDetectionNet(K), seed=3).double().train()
+    torch.manual_seed(0)
+    net = synth.fill_detection_net_(V.ObjectDetectionNet(K), seed=3).to(DEV).train()
+    assert [n for n, _ in net.named_parameters()] == [n for n, _ in o32.named_parameters()]
+    anchors, reg, clas = net(x.to(DEV))
+    loss = V.SSD_loss(0.5, 0.25, 2.0)([anchors, reg, clas], [B.to(DEV), Cc.to(DEV)])
+    loss.backward()
+    a32, r32, c32 = o32(x)
+    l32 = RM.ssd_loss(a32, r32, c32, B, Cc, 0.5, 0.25, 2.0)[0]
+    l32.backward()
+    a64, r64, c64 = o64(x.double())
+    l64 = RM.ssd_loss(a64, r64, c64, B.double(), Cc, 0.5, 0.25, 2.0)[0]
+    l64.backward()
+    assert anchors.shape[0] == 49104 and torch.equal(anchors.cpu(), a32)
+    for name, hip, c, d in (('reg', reg, r32, r64), ('clas', clas, c32, c64), ('loss', loss, l32, l64)):
+        hip, c, d = hip.detach().cpu().double(), c.detach().double(), d.detach()
+        gap = (c - d).abs()
+        tol = 3 * torch.clamp(gap, min=torch.quantile(gap.reshape(-1)[:4000000], 0.95).item() if gap.numel() > 1 else 0.0) + 1e-3 * d.abs()
+        assert ((hip - d).abs() <= tol).all(), '%s: worst err/tol %.2f' % (name, ((hip - d).abs() / tol).max().item())
+    worst = 0.0
+    for (n, pp), (_, p32), (_, p64) in zip(net.named_parameters(), o32.named_parameters(), o64.named_parameters()):
+        g64, g32, gp = p64.grad, p32.grad.double(), pp.grad.detach().cpu().double()
+        e_hip, e_cpu, ref = (gp - g64).norm().item(), (g32 - g64).norm().item(), g64.norm().item()
+        worst = max(worst, e_hip / max(ref, 1e-300))
+        assert e_hip <= 3 * e_cpu + 1e-3 * ref, '%s: |hip-f64| %.3e vs |cpu32-f64| %.3e (|f64| %.3e)' % (n, e_hip, e_cpu, ref)
+    print('worst relative gradient error vs fp64: %.2e' % worst)

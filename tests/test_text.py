@@ -241,3 +241,54 @@ def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, mo
     assert_close(runs[0][1], cd.detach(), 1e-4, 1e-5, 'cT')
     assert_close(runs[0][2], xd.grad, 1e-3, 1e-4 * xd.grad.abs().max().item(), 'dx')
     assert_close(runs[0][3], ref.weight_hh_l0.grad, 1e-3, 1e-4 * ref.weight_hh_l0.grad.abs().max().item(), 'dW_hh')
+
+
+@pytest.mark.gpu
+def test_language_model_full_baseline_size_vs_oracle_fp64():
+    """BASELINE configs[3] assembled at its own size — LanguageModelNet 400 / 1150 / 3 layers, V = 47 343, bs 64, bptt 70, every
+    dropout mask injected (embedding rows, locked embedding / hidden / decoder masks, the three weight-drop masks) — one
+    forward + RegSeqCrossEntropyLoss(2, 1) + backward of the HIP path against the CPU oracle run in fp32 AND fp64 on the same
+    weights, tokens and masks.  Per parameter gradient: ||hip - f64|| <= 3 ||cpu32 - f64|| + 1e-3 ||f64|| (as far from the exact
+    answer as torch's own fp32 run, x3, plus north_star's 1e-3); loss and cross-entropy likewise."""
+    from neuralnetworklibrary_amd.Applications.Text import LanguageModelNet, RegSeqCrossEntropyLoss, _Vocab
+    V, bs, bptt, E, H = 47343, 64, 70, 400, 1150
+    stoi = {i: i for i in range(V)}
+    stoi['_pad_'] = 1
+    del stoi[1]
+    torch.manual_seed(11)
+    net = LanguageModelNet(_Vocab(stoi, bs))                     # the product's (= the reference's) initialisation
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    o32 = RT.LanguageModelNet(V, 1, bs)
+    o64 = RT.LanguageModelNet(V, 1, bs).double()
+    o32.load_state_dict(sd)
+    o64.load_state_dict({k: v.double() for k, v in sd.items()})
+    g = torch.Generator().manual_seed(12)
+    x, y = torch.randint(4, V, (bs, bptt), generator=g), torch.randint(4, V, (bs, bptt), generator=g)
+    keep = lambda shape, p: torch.bernoulli(torch.full(shape, 1 - p), generator=g) / (1 - p)
+    sizes = [E, H, H, E]
+    masks = {'emb_rows': keep((V, 1), 0.035), 'emb_locked': keep((1, bs, E), 0.175),
+             'weights': [keep((4 * sizes[i + 1], sizes[i + 1]), 0.14) for i in range(3)],
+             'hidden': [keep((1, bs, sizes[i + 1]), 0.105) for i in range(3)]}
+    dec_mask = keep((1, bs, E), 0.07)
+    to = lambda m, f: {k: ([f(t) for t in v] if isinstance(v, list) else f(v)) for k, v in m.items()}
+    net = net.to(DEV).train()
+    net.enc.fixed_masks, net.dec.fixed_mask = to(masks, lambda t: t.to(DEV)), dec_mask.to(DEV)
+    lf = RegSeqCrossEntropyLoss(2.0, 1.0)
+    loss_p = lf(net(x.to(DEV)), y.to(DEV))
+    loss_p.backward()
+    l32, ce32 = RT.reg_seq_cross_entropy(o32.train()(x, masks, dec_mask), y, 2.0, 1.0)
+    l32.backward()
+    l64, ce64 = RT.reg_seq_cross_entropy(o64.train()(x, to(masks, lambda t: t.double()), dec_mask.double()), y, 2.0, 1.0)
+    l64.backward()
+    for name, hip, c32, c64 in (('loss', loss_p.item(), l32.item(), l64.item()), ('ce', float(lf.cross_entropy), ce32.item(), ce64.item())):
+        assert abs(hip - c64) <= 3 * abs(c32 - c64) + 1e-3 * abs(c64), '%s: hip %.8f cpu32 %.8f f64 %.8f' % (name, hip, c32, c64)
+    worst = 0.0
+    for (n, pp), (_, p32), (_, p64) in zip(net.named_parameters(), o32.named_parameters(), o64.named_parameters()):
+        g64, g32, gp = p64.grad, p32.grad.double(), pp.grad.detach().cpu().double()
+        e_hip, e_cpu, ref = (gp - g64).norm().item(), (g32 - g64).norm().item(), g64.norm().item()
+        worst = max(worst, e_hip / max(ref, 1e-300))
+        assert e_hip <= 3 * e_cpu + 1e-3 * ref, '%s: |hip-f64| %.3e vs |cpu32-f64| %.3e (|f64| %.3e)' % (n, e_hip, e_cpu, ref)
+    for i in range(3):                                            # the carried state the next minibatch starts from (Text.py:547-550)
+        assert_close(net.enc.h[i], o64.enc.h[i].float(), 1e-3, 1e-5, 'carried h%d' % i)
+        assert_close(net.enc.c[i], o64.enc.c[i].float(), 1e-3, 1e-5, 'carried c%d' % i)
+    print('worst relative gradient error vs fp64: %.2e' % worst)
