@@ -271,15 +271,12 @@ int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, const int32_t*
  * match_anchors_objects :1474-1511, jaccard :234-256, focal_loss_retina :1513-1530, smoothL1_loss_retina :1532-1566).
  * anchors [A,4]; reg [bs,A,4]; clas [bs,A,K] (probabilities); boxes [bs,M,4], cats int64 [bs,M], both padded with -1
  * (Vision.py:798-809), M <= 128.  Outputs: out[3] = {(1-beta)*reg + beta*clas, reg_loss, clas_loss} (batch means),
- * state int32 [bs,A] (>=0 matched object, -1 negative, -2 ignored) and npos float [bs] are kept for backward.
- * ticket: one int32 of device memory owned by the caller, ZERO on entry and left zero on exit (the forward is one launch:
- * the last block to finish reduces the per-block partial sums, in an order that does not depend on which block that is);
- * launches that share a ticket must be ordered on one stream. */
+ * state int32 [bs,A] (>=0 matched object, -1 negative, -2 ignored) and npos float [bs] are kept for backward. */
 size_t nnl_retina_loss_workspace_bytes(int64_t bs, int64_t A);
 int nnl_retina_loss_fwd(const float* anchors, const float* reg, const float* clas, const float* boxes,
                         const int64_t* cats, int32_t* state, float* npos, float* out, int64_t bs, int64_t A,
                         int64_t K, int64_t M, float beta, float alpha, float gamma, void* workspace,
-                        size_t workspace_bytes, int32_t* ticket, void* stream);
+                        size_t workspace_bytes, void* stream);
 /* dreg [bs,A,4], dclas [bs,A,K] = d out[0] / d reg, d clas times *grad_out (device scalar). */
 int nnl_retina_loss_bwd(const float* anchors, const float* reg, const float* clas, const float* boxes,
                         const int64_t* cats, const int32_t* state, const float* npos, const float* grad_out,

@@ -1,6 +1,7 @@
 // K6 — fused RetinaNet detection loss: anchor/object matching + focal loss + smooth-L1 box loss for a whole batch,
-// forward in ONE launch (the last block to finish reduces the per-block partial sums in a fixed order), backward in one
-// launch, no host synchronisation.
+// forward in one launch plus a one-block fixed-order finalize, backward in one launch, no host synchronisation.  (Folding the
+// finalize into the forward with ticket hand-overs was measured SLOWER: the chain "last chunk -> image sum -> batch sum" is
+// three dependent device-scope round trips at the very end of the kernel, ~15 us with the chip idle; a second launch costs ~4.)
 // Replaces SSD_loss.__call__ -> ssd1 -> match_anchors_objects / focal_loss_retina / smoothL1_loss_retina
 // (Applications/Vision.py:1474-1511, 1513-1530, 1532-1566, 1568-1605, 1620-1644) whose reference form is a Python
 // loop over images (:1636), a Python loop over positive anchors (:1593) and two .nonzero() syncs per image.
@@ -27,14 +28,17 @@ namespace {
 
 constexpr int kBlock = 256;    // threads per block = anchors per chunk
 constexpr int kMaxObj = 128;   // objects per image held in LDS
+constexpr int kPre = 8;        // 16-B clas pieces per lane fetched ahead of the matching (K <= 32: the whole chunk)
 
-__device__ __forceinline__ float block_sum(float v, float* red) {
-  v = nnl_wave_sum(v);
+// block-wide sums of three values with one LDS exchange (red: 12 floats); fixed tree => deterministic
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float* red) {
+  a = nnl_wave_sum(a); b = nnl_wave_sum(b); c = nnl_wave_sum(c);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[wave] = a; red[4 + wave] = b; red[8 + wave] = c; }
   __syncthreads();
-  if (lane == 0) red[wave] = v;
-  __syncthreads();
-  return (red[0] + red[1]) + (red[2] + red[3]);
+  a = (red[0] + red[1]) + (red[2] + red[3]);
+  b = (red[4] + red[5]) + (red[6] + red[7]);
+  c = (red[8] + red[9]) + (red[10] + red[11]);
 }
 
 struct Encoded { float t[4]; };
@@ -92,42 +96,84 @@ template <bool G2>
 __device__ __forceinline__ float focal_term(float x, bool is_target, float alpha, float gamma) {
   const float p = fminf(fmaxf(x, 1e-4f), 1.0f - 1e-4f);
   const float q = 1.f - p;
-  return is_target ? -(alpha * powg<G2>(q, gamma)) * logf(p) : -((1.f - alpha) * powg<G2>(1.f - q, gamma)) * logf(q);
+  // target: -(alpha (1-p)^g) log p ; other: -((1-alpha) (1-q)^g) log q — ONE logf: select its argument, not its result
+  const float w = is_target ? alpha * powg<G2>(q, gamma) : (1.f - alpha) * powg<G2>(1.f - q, gamma);
+  return -w * logf(is_target ? p : q);
 }
 
 template <bool G2>
 __device__ __forceinline__ float focal_grad(float raw, bool is_target, float alpha, float gamma) {
-  if (!(raw >= 1e-4f && raw <= 1.0f - 1e-4f)) return 0.f;      // clamp passes gradient only inside its range
-  const float p = raw;
-  if (is_target) {                                              // L = -alpha (1-p)^g log p
-    const float q = 1.f - p;
-    return alpha * (gamma * powg1<G2>(q, gamma) * logf(p) - powg<G2>(q, gamma) / p);
-  }
-  return (1.f - alpha) * (-gamma * powg1<G2>(p, gamma) * logf(1.f - p) + powg<G2>(p, gamma) / (1.f - p));   // L = -(1-alpha) p^g log(1-p)
+  // target: L = -alpha (1-p)^g log p      => dL/dp =  alpha     (g (1-p)^(g-1) log p     - (1-p)^g / p)
+  // other : L = -(1-alpha) p^g log(1-p)   => dL/dp = -(1-alpha) (g p^(g-1)     log(1-p) - p^g / (1-p))
+  // one logf and one division: u = the log's argument, v = the power's base
+  const float u = is_target ? raw : 1.f - raw, v = is_target ? 1.f - raw : raw;
+  const float c = is_target ? alpha : -(1.f - alpha);
+  const float d = c * (gamma * powg1<G2>(v, gamma) * logf(u) - powg<G2>(v, gamma) / u);
+  return (raw >= 1e-4f && raw <= 1.0f - 1e-4f) ? d : 0.f;      // clamp passes gradient only inside its range
 }
 
-// grid: (chunks per image, bs).  part[(img*gridDim.x + chunk)*3 + {0,1,2}] = {focal sum, smoothL1 sum, #pos}; the block that
-// takes the last ticket reduces them per image in a fixed order and writes out[3] / npos[bs].  *ticket is 0 at rest.
+// one 16-B piece f of a chunk's flat clas stream: floats 4f .. 4f+3 belong to anchor (4f) / K (K % 4 == 0: never two anchors)
+template <bool G2>
+__device__ __forceinline__ float focal_piece(const float4 v, int f, int K, float inv_k, const int* s_t, float alpha, float gamma) {
+  const int e = 4 * f;
+  const int an = (int)(((float)e + 0.5f) * inv_k);              // e / K (exact: (e + .5) / K is >= .5 / K away from an integer)
+  const int k0 = e - an * K;
+  const int t = s_t[an];
+  if (t == -2) return 0.f;
+  return ((focal_term<G2>(v.x, k0 == t, alpha, gamma) + focal_term<G2>(v.y, k0 + 1 == t, alpha, gamma)) +
+          focal_term<G2>(v.z, k0 + 2 == t, alpha, gamma)) + focal_term<G2>(v.w, k0 + 3 == t, alpha, gamma);
+}
+
+template <bool G2>
+__device__ __forceinline__ float4 focal_grad_piece(const float4 v, int f, int K, float inv_k, const int* s_t, float alpha, float gamma,
+                                                   float gc) {
+  const int e = 4 * f;
+  const int an = (int)(((float)e + 0.5f) * inv_k);
+  const int k0 = e - an * K;
+  const int t = s_t[an];
+  float4 d = {0.f, 0.f, 0.f, 0.f};
+  if (t != -2) {
+    d.x = focal_grad<G2>(v.x, k0 == t, alpha, gamma) * gc;
+    d.y = focal_grad<G2>(v.y, k0 + 1 == t, alpha, gamma) * gc;
+    d.z = focal_grad<G2>(v.z, k0 + 2 == t, alpha, gamma) * gc;
+    d.w = focal_grad<G2>(v.w, k0 + 3 == t, alpha, gamma) * gc;
+  }
+  return d;
+}
+
+// grid: (chunks per image, bs).  part[(img*gridDim.x + chunk)*3 + {0,1,2}] = {focal sum, smoothL1 sum, #pos}
 template <bool G2>
 __global__ __launch_bounds__(kBlock) void retina_fwd_kernel(
     const float* __restrict__ anchors, const float* __restrict__ reg, const float* __restrict__ clas,
     const float* __restrict__ boxes, const int64_t* __restrict__ cats, int32_t* __restrict__ state,
-    float* __restrict__ part, int* __restrict__ ticket, float* __restrict__ out, float* __restrict__ npos_out,
-    int A, int K, int M, float alpha, float gamma, float beta) {
+    float* __restrict__ part, int A, int K, int M, float alpha, float gamma) {
   __shared__ float4 s_box[kMaxObj];
   __shared__ float s_area[kMaxObj];
   __shared__ int s_cat[kMaxObj];
   __shared__ int s_cnt[2];
   __shared__ int s_t[kBlock];           // per anchor of the chunk: target class (>= 0), -1 negative, -2 ignored / out of range
-  __shared__ float red[4];
-  __shared__ int s_last;
+  __shared__ float red[12];
   const int img = blockIdx.y, tid = threadIdx.x;
-  const int m = load_objects(boxes, cats, img, M, s_box, s_area, s_cat, s_cnt);
   const int a0 = blockIdx.x * kBlock, a = a0 + tid;
+  // every global load that does not depend on the matching is issued FIRST — the chunk's class probabilities (up to kPre 16-B
+  // pieces per lane: all of them at K <= 32) and this lane's anchor — so the object compaction, the IoU loop and the two
+  // barriers run under their latency instead of in front of it (a block is otherwise a chain of six dependent round trips)
+  const int n_anch = min(kBlock, A - a0);
+  const float* __restrict__ cp = clas + ((long)img * A + a0) * K;
+  const bool vec = (K & 3) == 0;
+  const int nv = vec ? n_anch * K / 4 : 0;
+  float4 pre[kPre];
+#pragma unroll
+  for (int i = 0; i < kPre; ++i) {
+    const int f = tid + i * kBlock;
+    if (f < nv) pre[i] = reinterpret_cast<const float4*>(cp)[f];
+  }
+  float4 an = {0.f, 0.f, 0.f, 0.f};
+  if (a < A) an = reinterpret_cast<const float4*>(anchors)[a];
+  const int m = load_objects(boxes, cats, img, M, s_box, s_area, s_cat, s_cnt);
   float focal = 0.f, sl1 = 0.f, np = 0.f;
   int tcls = -2;
   if (a < A) {
-    const float4 an = reinterpret_cast<const float4*>(anchors)[a];
     const float area_a = (an.z - an.x) * (an.w - an.y);
     float best = -1.f;
     int arg = 0;
@@ -161,77 +207,58 @@ __global__ __launch_bounds__(kBlock) void retina_fwd_kernel(
   s_t[tid] = tcls;
   __syncthreads();
   // the chunk's class probabilities as one flat stream
-  const int n_anch = min(kBlock, A - a0);
-  const float* __restrict__ cp = clas + ((long)img * A + a0) * K;
   const float inv_k = 1.f / (float)K;
-  if ((K & 3) == 0) {
-    const int nv = n_anch * K / 4;
-    for (int f = tid; f < nv; f += kBlock) {
-      const float4 v = reinterpret_cast<const float4*>(cp)[f];
-      const int e = 4 * f;
-      const int an = (int)(((float)e + 0.5f) * inv_k);          // e / K (exact: (e + .5) / K is >= .5 / K away from an integer)
-      const int k0 = e - an * K;
-      const int t = s_t[an];
-      if (t != -2) {
-        focal += focal_term<G2>(v.x, k0 == t, alpha, gamma);
-        focal += focal_term<G2>(v.y, k0 + 1 == t, alpha, gamma);
-        focal += focal_term<G2>(v.z, k0 + 2 == t, alpha, gamma);
-        focal += focal_term<G2>(v.w, k0 + 3 == t, alpha, gamma);
-      }
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      const int f = tid + i * kBlock;
+      if (f < nv) focal += focal_piece<G2>(pre[i], f, K, inv_k, s_t, alpha, gamma);
     }
+    for (int f = tid + kPre * kBlock; f < nv; f += kBlock)
+      focal += focal_piece<G2>(reinterpret_cast<const float4*>(cp)[f], f, K, inv_k, s_t, alpha, gamma);
   } else {
     const int ne = n_anch * K;
     for (int e = tid; e < ne; e += kBlock) {
-      const int an = (int)(((float)e + 0.5f) * inv_k);
-      const int t = s_t[an];
-      if (t != -2) focal += focal_term<G2>(cp[e], e - an * K == t, alpha, gamma);
+      const int an_i = (int)(((float)e + 0.5f) * inv_k);
+      const int t = s_t[an_i];
+      if (t != -2) focal += focal_term<G2>(cp[e], e - an_i * K == t, alpha, gamma);
     }
   }
-  focal = block_sum(focal, red);
-  sl1 = block_sum(sl1, red);
-  np = block_sum(np, red);
-  const int nblk = gridDim.x, bs = gridDim.y;
+  block_sum3(focal, sl1, np, red);
   if (tid == 0) {
-    // hand-over WITHOUT cache-wide fences (an acquire / release at agent scope writes back and invalidates the XCD's whole L2
-    // once per block: measured 111 us instead of ~25): the three partial sums go out as agent-scope (write-through) stores, are
-    // drained (vmcnt 0) before the ticket is taken, and the last block reads them with agent-scope loads
-    float* o = part + ((long)img * nblk + blockIdx.x) * 3;
-    __hip_atomic_store(o + 0, focal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(o + 1, sl1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(o + 2, np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == nblk * bs - 1;
+    float* o = part + ((long)img * gridDim.x + blockIdx.x) * 3;
+    o[0] = focal; o[1] = sl1; o[2] = np;
   }
-  __syncthreads();
-  if (!s_last) return;
-  // ---- finalize (one block): wave w reduces images w, w+4, ...; lane l adds partials l, l+64, ... then a fixed shuffle tree.
-  // The order depends only on (bs, nblk), never on which block came last.
-  const int lane = tid & 63, wave = tid >> 6;
+}
+
+// out[0] = total loss, out[1] = reg loss, out[2] = clas loss (batch means); npos[img] kept for backward.  ONE block of 16 waves:
+// wave w reduces images w, w+16, ...; lane l adds that image's partials l, l+64, ... then a fixed shuffle tree; thread 0 adds the
+// 16 wave results in order.  (The first version was one thread walking bs x nblk x 3 dependent loads: 232 us.)
+__global__ __launch_bounds__(1024) void retina_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               float* __restrict__ npos, int bs, int nblk, float beta) {
+  __shared__ float fin[32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float clas_sum = 0.f, reg_sum = 0.f;
-  for (int i = wave; i < bs; i += 4) {
+  for (int i = wave; i < bs; i += 16) {
     float f = 0.f, s = 0.f, n = 0.f;
     for (int b = lane; b < nblk; b += 64) {
-      float* p = part + ((long)i * nblk + b) * 3;
-      f += __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s += __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      n += __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float* p = part + ((long)i * nblk + b) * 3;
+      f += p[0]; s += p[1]; n += p[2];
     }
     f = nnl_wave_sum(f); s = nnl_wave_sum(s); n = nnl_wave_sum(n);
-    if (lane == 0) npos_out[i] = n;
+    if (lane == 0) npos[i] = n;
     clas_sum += f / fmaxf(n, 1.f);
     reg_sum += n > 0.f ? s / (n * 4.f) : 0.f;
   }
-  __shared__ float fin[8];
-  if (lane == 0) { fin[wave] = clas_sum; fin[4 + wave] = reg_sum; }
+  if (lane == 0) { fin[wave] = clas_sum; fin[16 + wave] = reg_sum; }
   __syncthreads();
-  if (tid == 0) {
-    const float c = ((fin[0] + fin[1]) + (fin[2] + fin[3])) / bs;
-    const float r = ((fin[4] + fin[5]) + (fin[6] + fin[7])) / bs;
+  if (threadIdx.x == 0) {
+    float c = 0.f, r = 0.f;
+    for (int w = 0; w < 16; ++w) { c += fin[w]; r += fin[16 + w]; }
+    c /= bs; r /= bs;
     out[1] = r;
     out[2] = c;
     out[0] = (1.f - beta) * r + beta * c;
-    __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero at rest for the next launch on this stream
   }
 }
 
@@ -247,16 +274,28 @@ __global__ __launch_bounds__(kBlock) void retina_bwd_kernel(
   __shared__ int s_cnt[2];
   __shared__ int s_t[kBlock];
   const int img = blockIdx.y, tid = threadIdx.x;
+  const int a0 = blockIdx.x * kBlock, a = a0 + tid;
+  const int n_anch = min(kBlock, A - a0);
+  const float* __restrict__ cp = clas + ((long)img * A + a0) * K;
+  float* __restrict__ dp = dclas + ((long)img * A + a0) * K;
+  const bool vec = (K & 3) == 0;
+  const int nv = vec ? n_anch * K / 4 : 0;
+  float4 pre[kPre];                                  // as in the forward: the chunk's clas pieces and the state are fetched first
+#pragma unroll
+  for (int i = 0; i < kPre; ++i) {
+    const int f = tid + i * kBlock;
+    if (f < nv) pre[i] = reinterpret_cast<const float4*>(cp)[f];
+  }
+  int st = -2;
+  if (a < A) st = state[(long)img * A + a];
   load_objects(boxes, cats, img, M, s_box, nullptr, s_cat, s_cnt);
   const float g = gup[0];
   const float n = npos[img];
   const float gc = g * beta / (bs * fmaxf(n, 1.f));
   const float gr = n > 0.f ? g * (1.f - beta) / (bs * n * 4.f) : 0.f;
-  const int a0 = blockIdx.x * kBlock, a = a0 + tid;
   int tcls = -2;
   if (a < A) {
     const long ia = (long)img * A + a;
-    const int st = state[ia];
     tcls = st >= 0 ? s_cat[st] : st;
     float4 dr = {0.f, 0.f, 0.f, 0.f};
     if (st >= 0) {
@@ -279,27 +318,15 @@ __global__ __launch_bounds__(kBlock) void retina_bwd_kernel(
   }
   s_t[tid] = tcls;
   __syncthreads();
-  const int n_anch = min(kBlock, A - a0);
-  const float* __restrict__ cp = clas + ((long)img * A + a0) * K;
-  float* __restrict__ dp = dclas + ((long)img * A + a0) * K;
   const float inv_k = 1.f / (float)K;
-  if ((K & 3) == 0) {
-    const int nv = n_anch * K / 4;
-    for (int f = tid; f < nv; f += kBlock) {
-      const int e = 4 * f;
-      const int an = (int)(((float)e + 0.5f) * inv_k);
-      const int k0 = e - an * K;
-      const int t = s_t[an];
-      float4 d = {0.f, 0.f, 0.f, 0.f};
-      if (t != -2) {
-        const float4 v = reinterpret_cast<const float4*>(cp)[f];
-        d.x = focal_grad<G2>(v.x, k0 == t, alpha, gamma) * gc;
-        d.y = focal_grad<G2>(v.y, k0 + 1 == t, alpha, gamma) * gc;
-        d.z = focal_grad<G2>(v.z, k0 + 2 == t, alpha, gamma) * gc;
-        d.w = focal_grad<G2>(v.w, k0 + 3 == t, alpha, gamma) * gc;
-      }
-      reinterpret_cast<float4*>(dp)[f] = d;
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      const int f = tid + i * kBlock;
+      if (f < nv) reinterpret_cast<float4*>(dp)[f] = focal_grad_piece<G2>(pre[i], f, K, inv_k, s_t, alpha, gamma, gc);
     }
+    for (int f = tid + kPre * kBlock; f < nv; f += kBlock)
+      reinterpret_cast<float4*>(dp)[f] = focal_grad_piece<G2>(reinterpret_cast<const float4*>(cp)[f], f, K, inv_k, s_t, alpha, gamma, gc);
   } else {
     const int ne = n_anch * K;
     for (int e = tid; e < ne; e += kBlock) {
@@ -322,10 +349,10 @@ extern "C" size_t nnl_retina_loss_workspace_bytes(int64_t bs, int64_t A) {
 extern "C" int nnl_retina_loss_fwd(const float* anchors, const float* reg, const float* clas, const float* boxes,
                                    const int64_t* cats, int32_t* state, float* npos, float* out, int64_t bs, int64_t A,
                                    int64_t K, int64_t M, float beta, float alpha, float gamma, void* workspace,
-                                   size_t workspace_bytes, int32_t* ticket, void* stream) {
+                                   size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(bs > 0 && A > 0 && K > 0 && M >= 0 && A < (1L << 30) && bs < 65536 && K <= 4096, "retina_loss_fwd: bad sizes");
   NNL_CHECK_ARG(M <= kMaxObj, "retina_loss_fwd: at most %d objects per image (got %ld)", kMaxObj, (long)M);
-  NNL_CHECK_ARG(anchors && reg && clas && state && npos && out && ticket && (M == 0 || (boxes && cats)), "retina_loss_fwd: null pointer");
+  NNL_CHECK_ARG(anchors && reg && clas && state && npos && out && (M == 0 || (boxes && cats)), "retina_loss_fwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_retina_loss_workspace_bytes(bs, A))
     return nnl_set_error(NNL_ERR_WORKSPACE, "retina_loss_fwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -333,10 +360,12 @@ extern "C" int nnl_retina_loss_fwd(const float* anchors, const float* reg, const
   NnlProfScope prof(NNL_PROF_RETINA_LOSS, s, (double)bs * A * (16 + 16 + 4.0 * K + 4));
   if (gamma == 2.f)
     hipLaunchKernelGGL(retina_fwd_kernel<true>, grid, dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state, (float*)workspace,
-                       (int*)ticket, out, npos, (int)A, (int)K, (int)M, alpha, gamma, beta);
+                       (int)A, (int)K, (int)M, alpha, gamma);
   else
     hipLaunchKernelGGL(retina_fwd_kernel<false>, grid, dim3(kBlock), 0, s, anchors, reg, clas, boxes, cats, state, (float*)workspace,
-                       (int*)ticket, out, npos, (int)A, (int)K, (int)M, alpha, gamma, beta);
+                       (int)A, (int)K, (int)M, alpha, gamma);
+  NNL_CHECK_LAUNCH();
+  hipLaunchKernelGGL(retina_finalize_kernel, dim3(1), dim3(1024), 0, s, (const float*)workspace, out, npos, (int)bs, (int)grid.x, beta);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

@@ -785,19 +785,6 @@ def embedding_renorm_drop(x, weight, mask, max_norm):
 # ---------------------------------------------------------------------------------------------------------
 # K6 fused RetinaNet loss
 # ---------------------------------------------------------------------------------------------------------
-_RETINA_TICKETS = {}
-
-
-def _retina_ticket(device):
-    "the forward kernel's zero-at-rest ticket word (include/nnl.h, K6): one per device, every launch is on torch's current stream"
-    t = _RETINA_TICKETS.get(device.index)
-    if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise _lib.NnlError('retina_loss: first call under stream capture (run one eager step first)')
-        t = _RETINA_TICKETS[device.index] = torch.zeros(1, dtype=torch.int32, device=device)
-    return t
-
-
 class _RetinaLoss(torch.autograd.Function):
     """SSD_loss.__call__ (reference Applications/Vision.py:1620-1644 and everything below it) as one fused forward
     kernel and one fused backward kernel; returns [total, reg_loss, clas_loss].  Gradient flows through `total`."""
@@ -816,8 +803,7 @@ class _RetinaLoss(torch.autograd.Function):
         wsb = int(lib.nnl_retina_loss_workspace_bytes(bs, A))
         ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=dev)
         check(lib.nnl_retina_loss_fwd(ptr(anchors), ptr(reg), ptr(clas), ptr(boxes), ptr(cats), ptr(state), ptr(npos), ptr(out),
-                                      bs, A, K, M, float(beta), float(alpha), float(gamma), ptr(ws), wsb, ptr(_retina_ticket(dev)),
-                                      stream()))
+                                      bs, A, K, M, float(beta), float(alpha), float(gamma), ptr(ws), wsb, stream()))
         ctx.save_for_backward(anchors, reg, clas, boxes, cats, state, npos)
         ctx.hyper = (float(beta), float(alpha), float(gamma))
         return out

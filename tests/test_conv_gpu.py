@@ -31,6 +31,15 @@ CASES = [
     (2, 32, 15, 15, 32, 3, 2, 1, False, False),     # strided dgrad, odd size: one launch per output-parity class
     (2, 16, 24, 20, 16, 7, 2, 3, False, False),     # strided dgrad, 49 taps in four parity classes of ONE launch
     (3, 256, 16, 16, 256, 3, 2, 1, True, False),    # RetinaNet P6: merged classes on the BK=32 kernel
+    (2, 256, 4, 4, 256, 3, 1, 1, True, True),       # RetinaNet head tower on P7 at 512x512: 32 output pixels
+    (2, 256, 8, 8, 256, 3, 1, 1, True, True),       # ... on P6
+    (2, 256, 64, 64, 256, 3, 1, 1, True, True),     # ... on P3 (the bulk of the head FLOPs)
+    (2, 256, 4, 4, 36, 3, 1, 1, True, False),       # regression output conv on P7
+    (2, 256, 32, 32, 256, 3, 1, 1, True, True),     # head tower on P4 / P5 at 512x512, 2 images: 128- and 32-tile grids
+    (2, 256, 16, 16, 256, 3, 1, 1, True, True),
+    (16, 256, 16, 16, 256, 3, 1, 1, True, True),    # ... at the benchmark's 16 images
+    (16, 256, 8, 8, 256, 3, 1, 1, True, True),
+    (16, 256, 4, 4, 256, 3, 1, 1, True, True),
 ]
 
 

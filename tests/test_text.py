@@ -257,11 +257,12 @@ def test_language_model_full_baseline_size_vs_oracle_fp64():
     del stoi[1]
     torch.manual_seed(11)
     net = LanguageModelNet(_Vocab(stoi, bs))                     # the product's (= the reference's) initialisation
-    sd = {k: v.clone() for k, v in net.state_dict().items()}
     o32 = RT.LanguageModelNet(V, 1, bs)
+    sd = {k: v.clone() for k, v in net.state_dict().items() if k in o32.state_dict()}     # (the product's `head` aliases `dec`)
     o64 = RT.LanguageModelNet(V, 1, bs).double()
     o32.load_state_dict(sd)
     o64.load_state_dict({k: v.double() for k, v in sd.items()})
+    o64.enc.h, o64.enc.c = [t.double() for t in o64.enc.h], [t.double() for t in o64.enc.c]      # (carried state: plain tensors)
     g = torch.Generator().manual_seed(12)
     x, y = torch.randint(4, V, (bs, bptt), generator=g), torch.randint(4, V, (bs, bptt), generator=g)
     keep = lambda shape, p: torch.bernoulli(torch.full(shape, 1 - p), generator=g) / (1 - p)
