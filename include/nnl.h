@@ -39,6 +39,9 @@ typedef enum {
 
 int nnl_version(void);
 const char* nnl_last_error(void);
+/* The NNL_* tuning / A-B environment switches are read once per call site; this makes every site read its variable again
+ * (tests and the A/B tools change a switch inside one process). */
+int nnl_reload_env(void);
 
 /* ---- profiling hooks (bench.py roofline leg): HIP events recorded on the launch stream --------- */
 enum { NNL_PROF_CONV_FWD = 0, NNL_PROF_CONV_DGRAD = 1, NNL_PROF_CONV_WGRAD = 2, NNL_PROF_EMBDOT = 3,
@@ -292,18 +295,24 @@ int nnl_retina_loss_bwd(const float* anchors, const float* reg, const float* cla
  * w_hh_pad [4H, Hp] = (dropped) W_hh with zero-padded rows; h0, c0 [B,H].  Outputs y [T,B,H] (h_t), cy [T,B,H] (c_t)
  * and gates [T,B,4H] (ACTIVATED i,f,g,o) — the last two are saved for backward.
  * One kernel launch per timestep: the recurrent GEMM runs in k slices over <= 256 workgroups and the workgroup that finishes
- * a tile last (atomic ticket, nobody waits) sums the slices in a fixed order and applies the cell (csrc/lstm.hip). */
+ * a tile last (atomic ticket, nobody waits) sums the slices in a fixed order and applies the cell (csrc/lstm.hip).
+ * PERSISTENT path (csrc/lstm_persist.hip; B <= 64 and the per-workgroup W_hh slice fits the LDS — the AWD-LSTM shapes): ONE
+ * cooperative launch per layer and direction; ceil(H/U) <= 256 workgroups keep their 4U rows of W_hh in LDS for all T steps,
+ * exchange h_t through a k-major buffer with one slot per timestep and meet at a grid barrier per step.
+ * err_flag: one int32 of device memory (may be NULL: per-timestep path only); a persistent launch whose grid barrier times out
+ * sets it to 2 and drains. */
 int64_t nnl_lstm_padded_hidden(int64_t H);
 int64_t nnl_lstm_padded_gates(int64_t H);
 size_t nnl_lstm_workspace_bytes(int64_t T, int64_t B, int64_t H);
 int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
-                 float* gates, int64_t T, int64_t B, int64_t H, void* workspace, size_t workspace_bytes, void* stream);
+                 float* gates, int64_t T, int64_t B, int64_t H, void* workspace, size_t workspace_bytes, int32_t* err_flag,
+                 void* stream);
 /* BPTT: dy [T,B,H] (may be NULL), dhT / dcT [B,H] (may be NULL = 0), w_hh_t_pad [H, Gp] = W_hh^T with zero-padded rows.
  * Outputs dgates_pad [T,B,Gp] (columns < 4H: gradient of the PRE-activation gates = d gx; columns >= 4H are not written
  * and must be zero on entry; the caller derives dW_ih, dW_hh, db, dx from it with the GEMM entry points), dh0, dc0 [B,H]. */
 int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy,
                  const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, int64_t T, int64_t B,
-                 int64_t H, void* workspace, size_t workspace_bytes, void* stream);
+                 int64_t H, void* workspace, size_t workspace_bytes, int32_t* err_flag, void* stream);
 
 /* ---- K5b: embedding with per-vocabulary-row dropout mask, fused softmax + cross-entropy -----------------------
  * nnl_embedding_rowmask_*: EmbeddingDropout.forward, F.embedding(x, W * mask[V,1], pad) (Text.py:465-475):

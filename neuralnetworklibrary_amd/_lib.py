@@ -34,6 +34,7 @@ class ConvGeom(C.Structure):
 SIGNATURES = {
     'nnl_version': (C.c_int, []),
     'nnl_last_error': (C.c_char_p, []),
+    'nnl_reload_env': (C.c_int, []),
     'nnl_prof_enable': (C.c_int, [C.c_int]),
     'nnl_prof_collect': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
     'nnl_embdotbias_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int, f32, f32,
@@ -73,8 +74,8 @@ SIGNATURES = {
     'nnl_lstm_padded_hidden': (i64, [i64]),
     'nnl_lstm_padded_gates': (i64, [i64]),
     'nnl_lstm_workspace_bytes': (sz, [i64, i64, i64]),
-    'nnl_lstm_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p]),
-    'nnl_lstm_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p]),
+    'nnl_lstm_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
+    'nnl_lstm_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_embedding_rowmask_fwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, c_p, c_p]),
     'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p]),
     'nnl_softmax_ce_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p, c_p]),

@@ -36,7 +36,7 @@ int launch_rowk(IgemmRowkParams p, hipStream_t s) {
 template <int MODE>
 int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   // tuning hook (tools/bench_conv.py): NNL_IGEMM_TILE=0..3 forces 128x128 / 128x64 / 64x128 / 64x64
-  const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
+  const int forced = NNL_ENV_INT("NNL_IGEMM_TILE", -1);
   switch (forced) {
     case 0: return launch_rowk<128, 128, 2, 2, MODE>(p, s);
     case 1: return launch_rowk<128, 64, 2, 2, MODE>(p, s);
@@ -54,20 +54,19 @@ int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   return launch_rowk<64, 64, 2, 2, MODE>(p, s);
 }
 
-static int os_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }   // A/B hooks, re-read per call
 
 // LDS-DMA staging of the 64x64 tile (igemm_taps.h): an experiment kept behind NNL_IGEMM_DMA (0 off = default, 1 BK=16 launches,
 // 2 BK=32 launches, 3 both).  Measured per ResNet-34 layer (bench_conv.py --ab NNL_IGEMM_DMA=0,3): +3.5 % on the 56x56 / C=64
 // stage, -1 % on 28x28 / C=128, -7 % with BK=32 (two buffers); inside the full training step the gain on the C=64 stage
 // does not show (15.44 ms/step either way), so register staging stays the shipped path.
 static bool taps_dma(int bk, const IgemmTapsParams&) {
-  const int m = os_env_int("NNL_IGEMM_DMA", 0);
+  const int m = NNL_ENV_INT("NNL_IGEMM_DMA", 0);
   return bk == 16 ? (m & 1) != 0 : (m & 2) != 0;
 }
 
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
-  { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
+  p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
   p.cls_tiles = p.grid_m * p.grid_n;
@@ -102,11 +101,11 @@ constexpr long kTileCounters = 65536;   // ints in the caller's persistent tile-
 BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   BalPlan best{};
   best.bm = bm;
-  const char* e = getenv("NNL_IGEMM_BALANCE");
-  if ((e && atoi(e) == 0) || Nc % 4 != 0) return best;
+  const int e_bal = NNL_ENV_INT("NNL_IGEMM_BALANCE", 1);
+  if (e_bal == 0 || Nc % 4 != 0) return best;
   const long gm = nnl_cdiv(M, bm), gn = nnl_cdiv(Nc, 64), T = gm * gn;
-  const char* e_bk = getenv("NNL_IGEMM_BK32");
-  const int bk = (bm == 64 && (e_bk ? atoi(e_bk) : (T < 1200 || C >= 256)) && C % 32 == 0) ? 32 : 16;
+  const int e_bk = NNL_ENV_INT("NNL_IGEMM_BK32", -1);
+  const int bk = (bm == 64 && (e_bk >= 0 ? e_bk : (T < 1200 || C >= 256)) && C % 32 == 0) ? 32 : 16;
   const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
   const double c_it = (bk == 32 ? 0.60 : 0.30) * (bm / 64);            // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
   const double occ = bm == 128 ? 5 : (bk == 32 ? 4 : 6);               // resident workgroups per CU (LDS- / VGPR-limited)
@@ -118,7 +117,7 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   };
   const double plain = wave_iters(T, I) * c_it;
   best.t_us = plain;
-  double best_t = plain * ((e && atoi(e) == 2) ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
+  double best_t = plain * (e_bal == 2 ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
   for (int ks = 1; ks <= 4; ks *= 2) {
     if (I / ks < 8) break;
     const long units = T * ks;
@@ -175,7 +174,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counters, hipStream_t s) {
-  { const char* e = getenv("NNL_IGEMM_VARIANT"); p.variant = e ? atoi(e) : 1; }   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
+  p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
   p.grid_m = (int)nnl_cdiv(p.M, pl.bm);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
   const int T = p.grid_m * p.grid_n;
@@ -221,7 +220,7 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
                   int* bn_rows = nullptr) {
   IgemmTapsParams p = p_in;
   if (bn_rows) *bn_rows = 0;
-  const char* e_tile = getenv("NNL_IGEMM_TILE"); const int forced = e_tile ? atoi(e_tile) : -1;
+  const int forced = NNL_ENV_INT("NNL_IGEMM_TILE", -1);
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
   int best = 0;
@@ -267,9 +266,9 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
       }
       // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
-      const char* e_bk = getenv("NNL_IGEMM_BK32");
+      const int e_bk = NNL_ENV_INT("NNL_IGEMM_BK32", -1);
       const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64) * (p.ncls > 1 ? p.ncls : 1);
-      const int bk32 = e_bk ? atoi(e_bk) : (blocks64 < 1200 || p.C >= 256);   // long k loops (C >= 256) gain from BK=32 on large grids too (RetinaNet heads)
+      const int bk32 = e_bk >= 0 ? e_bk : (blocks64 < 1200 || p.C >= 256);   // long k loops (C >= 256) gain from BK=32 on large grids too (RetinaNet heads)
       if (bk32 && p.C % 32 == 0) return launch_taps<64, 64, 32>(p, s);
       return launch_taps<64, 64>(p, s);
     }
@@ -437,7 +436,7 @@ struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split; };
 WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   struct Cand { int bm, bn; double cost; };                               // cost: time per FLOP relative to the 128x128 tile
   static const Cand cands[4] = {{128, 128, 1.00}, {128, 64, 1.08}, {64, 128, 1.08}, {64, 64, 1.10}};
-  const int forced = os_env_int("NNL_WGRAD_TILE", -1);                    // tuning hook (re-read per call): index into cands
+  const int forced = NNL_ENV_INT("NNL_WGRAD_TILE", -1);                    // tuning hook: index into cands
   const long max_splits = Kp / 256 > 0 ? Kp / 256 : 1;                    // at least 256 pixels (16 k-steps) per split
   WgradPlan pl{};
   double best_t = 1e300;
@@ -489,12 +488,11 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
     const long T = 128, gm = pl.grid_m, gn = pl.grid_n;
     const long fp_m = (T < gm ? T : gm) * pl.bm + nnl_cdiv(T, gm) * pl.bn;
     const long fp_n = nnl_cdiv(T, gn) * pl.bm + (T < gn ? T : gn) * pl.bn;
-    q.n_fast = os_env_int("NNL_WGRAD_NFAST", fp_n < fp_m ? 1 : 0);
+    { const int e_nf = NNL_ENV_INT("NNL_WGRAD_NFAST", -1); q.n_fast = e_nf >= 0 ? e_nf : (fp_n < fp_m ? 1 : 0); }
   }
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
-  const int bk32 = os_env_int("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
-  const char* e_pipe = getenv("NNL_WGRAD_PIPE");                     // A/B hook: 1 = software-pipelined fragment reads
-  const int pipe = e_pipe ? atoi(e_pipe) : 1;
+  const int bk32 = NNL_ENV_INT("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
+  const int pipe = NNL_ENV_INT("NNL_WGRAD_PIPE", 1);                 // A/B hook: 1 = software-pipelined fragment reads
   if (pl.bm == 128 && pl.bn == 128) {
     if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2, true>), grid, block, 0, s, q);
     else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);   // BK=32 measured -7 % here
@@ -741,7 +739,7 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
       }
     };
     // all classes in ONE launch when they have the same row count (even H, W): longest classes first
-    bool merged = ncls > 1 && os_env_int("NNL_DGRAD_MERGE", 1) != 0;
+    bool merged = ncls > 1 && NNL_ENV_INT("NNL_DGRAD_MERGE", 1) != 0;
     for (int i = 1; i < ncls && merged; ++i) merged = cls[i].P == cls[0].P && cls[i].Q == cls[0].Q;
     if (merged) {
       for (int i = 1; i < ncls; ++i)                        // insertion sort by decreasing tap count (<= 4 entries)

@@ -19,9 +19,24 @@
 // across steps): latency-bound; a persistent W_hh-resident kernel is the planned upgrade.
 #include "igemm_taps.h"
 
+// the persistent (one cooperative launch per layer and direction) path: lstm_persist.hip
+bool nnl_lstm_persist_ok(long B, long H, long Kp, long Gp);
+size_t nnl_lstm_persist_ws_floats(long T, long Kp, long Gp);
+hipError_t nnl_lstm_persist_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
+                                float* gates, long T, long B, long H, long Kp, long Gp, float* ws, int* err, hipStream_t s);
+hipError_t nnl_lstm_persist_bwd(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy,
+                                const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, long T, long B,
+                                long H, long Kp, long Gp, float* ws, int* err, hipStream_t s);
+
 namespace {
 
 constexpr int kBlock = 256;
+
+// NNL_LSTM_PERSIST: bit 0 = persistent forward, bit 1 = persistent backward.  Default 1: the persistent BPTT kernel is correct
+// (tests/test_text.py runs it) but measured slower than the per-timestep pair at H = 1150 (42 vs 25 us per step: every workgroup
+// must stream all of dgates_{t+1}, 1.2 MB, per step, and its U = 5 output columns leave the 4x4 MFMA chains latency-bound).
+bool persist_fwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 1) != 0; }
+bool persist_bwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 2) != 0; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -79,8 +94,7 @@ long ceil32(long x) { return nnl_cdiv(x, 32) * 32; }
 // (measured: 288 workgroups 10.8 ms/step of LSTM time, 216-250: 9.7 ms, 576: 11.4 ms)
 int pick_splits(long M, long N, long nk) {
   const long tiles = nnl_cdiv(M, 64) * nnl_cdiv(N, 64);
-  const char* e = getenv("NNL_LSTM_WG");                     // tuning hook: workgroup budget
-  const long target = e ? atol(e) : 256;
+  const long target = NNL_ENV_INT("NNL_LSTM_WG", 256);           // tuning hook: workgroup budget
   long s = target / tiles;
   if (s < 1) s = 1;
   if (s > nk) s = nk;
@@ -126,7 +140,12 @@ extern "C" int64_t nnl_lstm_padded_gates(int64_t H) { return ceil32(4 * H); }
 static size_t lstm_ws_floats(const Plan& p, long T, long B, long H) {
   const long fwd = 2 * B * p.Hp + (long)p.sf * p.fwd_slab + T * p.tf;
   const long bwd = (long)p.sb * p.bwd_slab + B * H + T * p.tb;
-  return (size_t)(fwd > bwd ? fwd : bwd);
+  size_t n = (size_t)(fwd > bwd ? fwd : bwd);
+  if (nnl_lstm_persist_ok(B, H, p.Hp, p.Gp)) {               // the persistent path's per-timestep exchange slots
+    const size_t pn = nnl_lstm_persist_ws_floats(T, p.Hp, p.Gp);
+    if (pn > n) n = pn;
+  }
+  return n;
 }
 
 extern "C" size_t nnl_lstm_workspace_bytes(int64_t T, int64_t B, int64_t H) {
@@ -136,7 +155,7 @@ extern "C" size_t nnl_lstm_workspace_bytes(int64_t T, int64_t B, int64_t H) {
 
 extern "C" int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy,
                             float* gates, int64_t T, int64_t B, int64_t H, void* workspace, size_t workspace_bytes,
-                            void* stream) {
+                            int32_t* err_flag, void* stream) {
   NNL_CHECK_ARG(T > 0 && B > 0 && H > 0 && 4 * H < (1 << 24), "lstm_fwd: bad sizes");
   NNL_CHECK_ARG(gx && w_hh_pad && h0 && c0 && y && cy && gates, "lstm_fwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_lstm_workspace_bytes(T, B, H))
@@ -148,6 +167,13 @@ extern "C" int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float*
   int* counters = (int*)(slabs + (long)p.sf * p.fwd_slab);
   const long BH = B * H, BG = B * 4 * H;
   NnlProfScope prof(NNL_PROF_LSTM, s, 2.0 * T * B * 4.0 * H * H);
+  if (persist_fwd_enabled() && err_flag != nullptr && nnl_lstm_persist_ok(B, H, p.Hp, p.Gp)) {
+    // one cooperative launch for the whole sequence; if the runtime refuses it (not co-resident, LDS attribute) nothing has
+    // run and the per-timestep path below takes over
+    if (nnl_lstm_persist_fwd(gx, w_hh_pad, h0, c0, y, cy, gates, T, B, H, p.Hp, p.Gp, (float*)workspace, err_flag, s) == hipSuccess)
+      return NNL_OK;
+    (void)hipGetLastError();
+  }
   hipLaunchKernelGGL(pad_copy_kernel, dim3(ew_grid(B * p.Hp)), dim3(kBlock), 0, s, h0, hbuf[0], (int)B, (int)H, p.Hp);
   NNL_CHECK_LAUNCH();
   NNL_CHECK_HIP(hipMemsetAsync(hbuf[1], 0, sizeof(float) * B * p.Hp, s));          // pad columns stay zero
@@ -171,7 +197,7 @@ extern "C" int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float*
 
 extern "C" int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy,
                             const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, int64_t T,
-                            int64_t B, int64_t H, void* workspace, size_t workspace_bytes, void* stream) {
+                            int64_t B, int64_t H, void* workspace, size_t workspace_bytes, int32_t* err_flag, void* stream) {
   NNL_CHECK_ARG(T > 0 && B > 0 && H > 0, "lstm_bwd: bad sizes");
   NNL_CHECK_ARG(gates && cy && c0 && w_hh_t_pad && dgates_pad && dh0 && dc0, "lstm_bwd: null pointer");
   if (workspace == nullptr || workspace_bytes < nnl_lstm_workspace_bytes(T, B, H))
@@ -183,11 +209,16 @@ extern "C" int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT,
   int* counters = (int*)(slabs + (long)p.sb * p.bwd_slab + BH);
   float* dc = dc0;                               // running d loss / d c_{t-1}, ends as dc0
   NnlProfScope prof(NNL_PROF_LSTM, s, 2.0 * T * B * 4.0 * H * H);
+  if (persist_bwd_enabled() && err_flag != nullptr && nnl_lstm_persist_ok(B, H, p.Hp, p.Gp)) {
+    if (nnl_lstm_persist_bwd(dy, dhT, dcT, gates, cy, c0, w_hh_t_pad, dgates_pad, dh0, dc0, T, B, H, p.Hp, p.Gp, (float*)workspace,
+                             err_flag, s) == hipSuccess)
+      return NNL_OK;
+    (void)hipGetLastError();                     // refused: the per-timestep path below reads the same gates / cy layout
+  }
   if (dcT) NNL_CHECK_HIP(hipMemcpyAsync(dc, dcT, sizeof(float) * BH, hipMemcpyDeviceToDevice, s));
   else NNL_CHECK_HIP(hipMemsetAsync(dc, 0, sizeof(float) * BH, s));
   NNL_CHECK_HIP(hipMemsetAsync(counters, 0, sizeof(int) * T * p.tb, s));
-  const char* e_f = getenv("NNL_LSTM_FUSED_BWD");              // tuning hook; default: two launches per backward timestep
-  const bool fused_bwd = e_f && atoi(e_f) == 1;
+  const bool fused_bwd = NNL_ENV_INT("NNL_LSTM_FUSED_BWD", 0) == 1;   // tuning hook; default: two launches per backward timestep
   if (fused_bwd) {
     // t = T-1: no recurrent term from a later step (only dhT, if any): the stand-alone cell kernel
     hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(ew_grid(BH)), dim3(kBlock), 0, s, dy ? dy + (T - 1) * BH : nullptr, dhT,

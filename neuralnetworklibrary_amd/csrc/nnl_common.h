@@ -34,6 +34,11 @@ int nnl_set_error(int code, const char* fmt, ...);
 
 static inline int64_t nnl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Tuning / A-B switches (NNL_* environment variables): read ONCE per site, not per launch (a getenv per call sits on the host's
+// launch path).  nnl_reload_env() — exported for tests and the A/B tools — makes every site read its variable again.
+int nnl_env_cached(const char* name, int dflt, int* value, int* generation);
+#define NNL_ENV_INT(name, dflt) ([]() -> int { static int v_ = 0, g_ = -1; return nnl_env_cached(name, dflt, &v_, &g_); }())
+
 // optional per-launch profiling with HIP events on the launch stream (bench.py roofline leg)
 void nnl_prof_begin(int kind, hipStream_t s);
 void nnl_prof_end(int kind, hipStream_t s, double work);

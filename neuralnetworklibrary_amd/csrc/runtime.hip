@@ -16,7 +16,18 @@ int nnl_set_error(int code, const char* fmt, ...) {
   return code;
 }
 
-extern "C" int nnl_version(void) { return 100; }
+extern "C" int nnl_version(void) { return 200; }
+
+static int g_env_generation = 0;
+int nnl_env_cached(const char* name, int dflt, int* value, int* generation) {
+  if (*generation != g_env_generation) {
+    const char* e = getenv(name);
+    *value = e ? atoi(e) : dflt;
+    *generation = g_env_generation;
+  }
+  return *value;
+}
+extern "C" int nnl_reload_env(void) { ++g_env_generation; return NNL_OK; }
 extern "C" const char* nnl_last_error(void) { return g_err; }
 
 // ---- profiling: a bounded pool of event pairs, recorded on the stream each kernel is launched on ----

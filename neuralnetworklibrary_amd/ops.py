@@ -31,8 +31,11 @@ def raise_if_index_error():
     last call saw an out-of-range index.  The Learner calls this at the end of every epoch, evaluate() and predict()
     (General/Learner.py `_raise_if_index_error`, which also makes the decision rank-uniform under data parallelism)."""
     for flag in _ERR_FLAGS.values():
-        if int(flag.item()) != 0:
+        v = int(flag.item())
+        if v != 0:
             flag.zero_()
+            if v == 2:
+                raise _lib.NnlError("the persistent LSTM kernel's grid barrier timed out (results of that step are invalid)")
             raise IndexError("index out of range in self")
 
 

@@ -44,3 +44,17 @@ def assert_close(actual, expected, rtol=1e-5, atol=1e-6, msg=''):
     if not (err <= tol).all():
         i = np.unravel_index(np.argmax(err - tol), err.shape) if err.ndim else ()
         raise AssertionError(f'{msg} max abs err {err.max():.3e} (at {i}: got {a[i]!r}, want {e[i]!r}); rtol={rtol} atol={atol}')
+
+
+@pytest.fixture(autouse=True)
+def _nnl_env_switches_fresh():
+    """the library caches its NNL_* switches per call site: re-read them around every test (tests change them with monkeypatch)"""
+    try:
+        from neuralnetworklibrary_amd._lib import lib
+    except Exception:
+        lib = None
+    if lib is not None:
+        lib.nnl_reload_env()
+    yield
+    if lib is not None:
+        lib.nnl_reload_env()

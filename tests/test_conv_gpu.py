@@ -123,10 +123,10 @@ def test_conv2d_balanced_schedule(case, monkeypatch):
     y_bal, dx_bal, dw_bal, dy = run()
     y_again = run()[0]
     assert torch.equal(y_bal, y_again), 'balanced schedule must be bitwise reproducible'
-    monkeypatch.setenv('NNL_IGEMM_BALANCE', '0')
+    monkeypatch.setenv('NNL_IGEMM_BALANCE', '0'); lib.nnl_reload_env()
     assert lib.nnl_conv2d_fwd_workspace_bytes(geom) == 0
     y_pl, dx_pl, dw_pl, _ = run()
-    monkeypatch.delenv('NNL_IGEMM_BALANCE')
+    monkeypatch.delenv('NNL_IGEMM_BALANCE'); lib.nnl_reload_env()
     sy, sx = y_pl.abs().max().item(), dx_pl.abs().max().item()
     assert_close(y_bal, y_pl, rtol=1e-5, atol=2e-6 * sy, msg='y balanced vs plain')
     assert_close(dx_bal, dx_pl, rtol=1e-5, atol=2e-6 * sx, msg='dx balanced vs plain')
@@ -184,6 +184,8 @@ def test_conv2d_lds_dma_staging_variant(case, monkeypatch):
     same convolution: forward / dgrad through `buffer_load ... lds` into the swizzled unpadded image, three (BK 16) or two
     (BK 32) buffers, on plain and balanced grids."""
     monkeypatch.setenv('NNL_IGEMM_DMA', '3')
+    from neuralnetworklibrary_amd._lib import lib
+    lib.nnl_reload_env()
     test_conv2d_fwd_bwd(case)
 
 

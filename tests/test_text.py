@@ -208,13 +208,19 @@ def test_embedding_rowmask_bit_exact_and_grad():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('fused_bwd', ['0', '1'])
-def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, monkeypatch):
-    """BASELINE-size layer (bs 64, bptt 70, 1150 -> 1150): the fused step kernel hands split-K partial tiles between
+@pytest.mark.parametrize('fused_bwd,persist', [('0', '1'), ('1', '0'), ('0', '3'), ('0', '0')])
+def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, persist, monkeypatch):
+    """BASELINE-size layer (bs 64, bptt 70, 1150 -> 1150) on every recurrence path: the persistent cooperative kernels
+    (lstm_persist.hip: 230 workgroups exchange h_t / dgates_t through per-timestep slots and meet at a grid barrier per step —
+    a stale read or a missed arrival would show as a run-to-run difference, a large error or the time-out flag) and the
+    per-timestep path, whose fused step kernel hands split-K partial tiles between
     workgroups (ticket + device-scope stores / loads, 72 tiles x 70 steps per pass); a stale hand-over would show up as a
     run-to-run difference or a large error.  Checked bitwise over repeated runs and against torch's LSTM in fp64."""
     from neuralnetworklibrary_amd import ops_text
+    from neuralnetworklibrary_amd._lib import lib
     monkeypatch.setenv('NNL_LSTM_FUSED_BWD', fused_bwd)       # '1': the (slower) fused backward step is kept tested too
+    monkeypatch.setenv('NNL_LSTM_PERSIST', persist)           # 1: persistent forward (default); 3: + persistent BPTT; 0: per-timestep
+    lib.nnl_reload_env()
     T, B, I, H = 70, 64, 1150, 1150
     g = torch.Generator().manual_seed(3)
     x = (torch.randn(T, B, I, generator=g) * 0.5)
@@ -241,6 +247,8 @@ def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, mo
     assert_close(runs[0][1], cd.detach(), 1e-4, 1e-5, 'cT')
     assert_close(runs[0][2], xd.grad, 1e-3, 1e-4 * xd.grad.abs().max().item(), 'dx')
     assert_close(runs[0][3], ref.weight_hh_l0.grad, 1e-3, 1e-4 * ref.weight_hh_l0.grad.abs().max().item(), 'dW_hh')
+    from neuralnetworklibrary_amd import ops
+    ops.raise_if_index_error()                                 # (also carries the persistent kernel's barrier time-out flag)
 
 
 @pytest.mark.gpu

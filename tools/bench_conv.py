@@ -66,6 +66,7 @@ def ab(args):
             for _ in range(5):
                 for v in vals:
                     os.environ[var] = v
+                    _lib.lib.nnl_reload_env()
                     res[v].append(timeit(fn, iters=5))
             med = {v: statistics.median(res[v]) for v in vals}
             for v in vals:

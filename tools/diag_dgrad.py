@@ -23,6 +23,7 @@ for N, C, H, W, K in GEOMS:
         for k in ('NNL_IGEMM_BALANCE', 'NNL_DGRAD_PAD16', 'NNL_IGEMM_TILE', 'NNL_IGEMM_VARIANT'):
             os.environ.pop(k, None)
         os.environ.update(st)
+        ops.lib.nnl_reload_env()
         xg, wg = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
         ops.conv2d(xg, wg, None, 1, 1).backward(dy.cuda())
         e = ((xg.grad.cpu().double() - xd.grad).norm() / xd.grad.norm()).item()
