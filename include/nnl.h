@@ -65,9 +65,13 @@ int nnl_embdotbias_fwd(const int64_t* x, const float* U, const float* M, const f
 /* Backward of the above = the four dense embedding_backward scatter-adds + sigmoid/mul backward
  * (autograd of CollabFiltering.py:198-203).  dU/dM/dbu/dbi are DENSE tables (nn.Embedding sparse=False,
  * General/Layers.py:59) which this call first zero-fills, then scatter-adds into. */
+/* Deterministic by default: with a workspace of nnl_*_bwd_workspace_bytes the samples that hit one table row are added in
+ * SAMPLE ORDER (rank sort + segment sum, csrc/scatter_det.h) — torch's CPU embedding_dense_backward order, bitwise reproducible.
+ * workspace == NULL (or NNL_SCATTER_ATOMIC=1, or more than 32768 samples): fp32 atomicAdd in arrival order. */
+size_t nnl_embdotbias_bwd_workspace_bytes(int64_t n);
 int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float* M, const float* z, const float* dy,
                        float* dU, float* dM, float* dbu, float* dbi, int64_t n, int64_t n_user,
-                       int64_t n_item, int64_t D, int has_range, float lo, float hi, void* stream);
+                       int64_t n_item, int64_t D, int has_range, float lo, float hi, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K1: conv2d as implicit GEMM on the exact-fp32 MFMA --------------------------------------------
  * Replaces the cuDNN convolutions called by nn.Conv2d inside BasicBlock.forward / Bottleneck.forward
@@ -263,11 +267,12 @@ int nnl_tab_gather_fwd(const int64_t* xcat, const float* const* tables, const in
                        int32_t n_cont, int32_t ld_out, void* stream);
 /* Backward: dense table gradients (nn.Embedding sparse=False) scatter-added into ONE flat zero-filled buffer
  * dtab_flat (table j at element offset grad_off[j]), and dcont [bs, n_cont] = dout[:, cat_width:] * cont_mask. */
+size_t nnl_tab_scatter_bwd_workspace_bytes(int64_t bs, int32_t ncat);      /* deterministic scatter: see nnl_embdotbias_bwd */
 int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, const int32_t* dim, const int32_t* col_off,
                         const int32_t* col_table, const int64_t* grad_off, const float* row_mask,
                         const float* cont_mask, const float* dout, float* dtab_flat, int64_t dtab_elems,
                         float* dcont, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out,
-                        void* stream);
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K6: fused RetinaNet detection loss (anchor matching + focal + smooth-L1) -----------------------------
  * Replaces SSD_loss.__call__ and everything it calls per image (Applications/Vision.py:1620-1644 -> ssd1 :1568-1605,
@@ -320,8 +325,9 @@ int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const floa
  * dout[i,:]*rowmask[x[i]] except for x[i] == padding_idx (pass -1 for none). */
 int nnl_embedding_rowmask_fwd(const int64_t* x, const float* W, const float* rowmask, float* out, int64_t n,
                               int64_t V, int64_t D, int32_t* err_flag, void* stream);
+size_t nnl_embedding_rowmask_bwd_workspace_bytes(int64_t n);               /* deterministic scatter: see nnl_embdotbias_bwd */
 int nnl_embedding_rowmask_bwd(const int64_t* x, const float* rowmask, const float* dout, float* dW, int64_t n,
-                              int64_t V, int64_t D, int64_t padding_idx, void* stream);
+                              int64_t V, int64_t D, int64_t padding_idx, void* workspace, size_t workspace_bytes, void* stream);
 /* F.cross_entropy(logits [rows,V], target [rows], reduction='mean') (Text.py:773; also nn.CrossEntropyLoss of
  * General/Learner.py:20): lse[r] = logsumexp, loss_rows[r] = lse[r] - logits[r,target[r]], *loss_mean = mean.
  * Backward: dlogits = (softmax - onehot) * (*grad_out) / rows. */

@@ -22,6 +22,7 @@ from ..General.Optimizer import *     # noqa: F401,F403
 from ..General.Core import TEN, separate_bn_layers
 from ..General.Layers import EmbeddingDrop, Flatten1d, FullyConnectedNet
 from .. import ops
+from ..dist import keyed_mask
 
 
 class StructuredDataset(Dataset):
@@ -134,10 +135,14 @@ class StructuredDataNet(nn.Module):
         row_masks = cont_mask = None
         p_emb = self.embeddings[0].drop.p if self.n_cat > 0 else 0
         if self.training and p_emb > 0:          # Layers.py:75-76: drop(ones(len(x))) per column
-            row_masks = torch.empty(self.n_cat, bs, device=device).bernoulli_(1 - p_emb).div_(1 - p_emb)
+            row_masks = keyed_mask((self.n_cat, bs), p_emb, device, sample_dim=1)       # None unless Learner.use_keyed_dropout()
+            if row_masks is None:
+                row_masks = torch.empty(self.n_cat, bs, device=device).bernoulli_(1 - p_emb).div_(1 - p_emb)
         p_cont = self.cont_drop.p
         if self.training and p_cont > 0 and self.n_cont > 0:
-            cont_mask = torch.empty(bs, self.n_cont, device=device).bernoulli_(1 - p_cont).div_(1 - p_cont)
+            cont_mask = keyed_mask((bs, self.n_cont), p_cont, device, sample_dim=0)
+            if cont_mask is None:
+                cont_mask = torch.empty(bs, self.n_cont, device=device).bernoulli_(1 - p_cont).div_(1 - p_cont)
         return row_masks, cont_mask
 
     def forward(self, xcat_batch, xcont_batch):

@@ -25,6 +25,7 @@ from ..General.Optimizer import *     # noqa: F401,F403
 from ..General.Core import TEN, correct_foldername, default_device, list_mult, separate_bn_layers
 from ..General.Layers import FullyConnectedNet
 from .. import ops
+from ..dist import keyed_mask
 
 
 # ---- data: language-model batches (Text.py:231-332) ----------------------------------------------------------------
@@ -106,6 +107,8 @@ class LockedDropout(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, mask=None):
+        if mask is None and self.training and self.drop.p > 0:
+            mask = keyed_mask((1, x.size(1), x.size(2)), self.drop.p, x.device, sample_dim=1)      # None unless use_keyed_dropout()
         if mask is None:
             mask = self.drop(torch.ones(1, x.size(1), x.size(2), device=x.device))
         return mask * x
@@ -127,6 +130,8 @@ class EmbeddingDropout(nn.Module):
         # x: [seqlen, bs] -> [seqlen, bs, emb_dim]
         if not self.training:
             return ops.embedding_rowmask(x, self.embed.weight, None, self.pad_token)
+        if row_mask is None and self.drop1.p > 0:
+            row_mask = keyed_mask((self.vocab_size, 1), self.drop1.p, x.device)     # parameter-shaped: the same on every rank
         if row_mask is None:
             row_mask = self.drop1(torch.ones(self.vocab_size, 1, device=x.device))
         out = ops.embedding_rowmask(x, self.embed.weight, row_mask, self.pad_token)
@@ -170,6 +175,8 @@ class WeightDropLSTM1(nn.Module):
 
     def forward(self, x, h0c0, weight_mask=None):
         p = self.lstm
+        if weight_mask is None and self.training and self.weight_drop.p > 0:
+            weight_mask = keyed_mask(p.weight_hh_l0_raw.shape, self.weight_drop.p, p.weight_hh_l0_raw.device)   # None unless keyed
         w_hh = self.weight_drop(p.weight_hh_l0_raw) if weight_mask is None else p.weight_hh_l0_raw * weight_mask
         return ops.lstm_layer(x, h0c0[0], h0c0[1], p.weight_ih_l0, w_hh, p.bias_ih_l0, p.bias_hh_l0)
 

@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .Core import initialize_modules
+from ..dist import KeyedDropout, keyed_mask
 
 __all__ = ['Flatten', 'Flatten1d', 'Linear', 'Conv2d', 'get_embedding', 'EmbeddingDrop', 'AdaptiveConcatPool2d',
            'FullyConnectedNet']
@@ -50,7 +51,7 @@ class Linear(nn.Module):
         super().__init__()
         self.lin = nn.Linear(nin, nout)
         self.bn = nn.BatchNorm1d(nout) if bn else None
-        self.drop = nn.Dropout(drop) if drop else None
+        self.drop = KeyedDropout(drop) if drop else None
 
     def forward(self, x):
         if self.drop:
@@ -67,7 +68,7 @@ class Conv2d(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(nin, nout, ks, stride, pad)
         self.bn = nn.BatchNorm2d(nout) if bn else None
-        self.drop = nn.Dropout(drop) if drop else None
+        self.drop = KeyedDropout(drop) if drop else None
 
     def forward(self, x):
         if self.drop:
@@ -90,6 +91,10 @@ class EmbeddingDrop(nn.Module):
 
     def row_mask(self, n, device):
         "the reference's `drop(ones(len(x)))`: 0 or 1/(1-p) per sample row"
+        if self.training and self.drop.p > 0:
+            m = keyed_mask((n,), self.drop.p, device, sample_dim=0)
+            if m is not None:
+                return m
         return self.drop(torch.ones(n, device=device))
 
     def forward(self, x):
@@ -125,7 +130,7 @@ class FullyConnectedNet(nn.Module):
         self.output_range = output_range
         self.pre_bn = nn.BatchNorm1d(layer_sizes[0]) if pre_bn else None
         self.lins = nn.ModuleList([Linear(layer_sizes[i], layer_sizes[i + 1], bn, drops[i]) for i in range(N - 1)])
-        self.final_drop = nn.Dropout(drops[N - 1])
+        self.final_drop = KeyedDropout(drops[N - 1])
         self.final_lin = nn.Linear(layer_sizes[N - 1], layer_sizes[N])
         initialize_modules([self.lins, self.final_lin], nn.init.kaiming_normal_, False)
 

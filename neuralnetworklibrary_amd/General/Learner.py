@@ -216,6 +216,17 @@ class Learner(object):
         nnl_dist.enable_sync_renorm(self.model, capacity=self.data.bs)     # tabular max_norm renorm over all ranks' lookups
         return self
 
+    def use_keyed_dropout(self, seed=0, flag=True):
+        """MI355X addition: draw every dropout mask of the product layers — EmbeddingDrop row masks, the
+        tabular continuous mask, nn.Dropout in the heads, LockedDropout, the vocabulary-row mask and the LSTM weight drop — as a
+        pure function of (seed, training step, request index, element index in the GLOBAL minibatch) instead of torch's per-process
+        RNG stream, so that an N-rank data-parallel run with dropout ON reproduces the 1-rank run (see dist.keyed_mask).  Off by
+        default: the reference's masks come from torch's stream."""
+        from .. import dist as nnl_dist
+        nnl_dist.drop_ctx.enabled, nnl_dist.drop_ctx.seed = bool(flag), int(seed)
+        self._kd_step = 0
+        return self
+
     def use_graphs(self, flag=True, warmup=2):
         """MI355X addition: capture the WHOLE training step (forward, loss, backward, fused optimizer) in a hipGraph after
         `warmup` eager steps per input shape and replay it afterwards — for the launch-bound heads (collaborative
@@ -493,12 +504,23 @@ class Learner(object):
         (General/Learner.py:490-516)."""
         bs = _batch_size(y_batch)
         self._dp_weight = 1.0
+        kd_offset = 0
         if self.grad_sync is not None:
             local, bs, full_bs, world = self._dp_batch_sizes(bs)
             # this rank's share of the global minibatch relative to an equal split (SURVEY.md §8e: local_bs / global_bs weighting)
             self._dp_weight = local * world / max(bs, 1)
+            if getattr(self.data.train_dl, 'dp_info', None) is not None:
+                from ..dist import shard_bounds
+                kd_offset = shard_bounds(bs, _rank(), world)[0]
+            else:
+                kd_offset = _rank() * local
         else:
             full_bs = self.data.bs
+        if getattr(self, '_kd_step', None) is not None:
+            from ..dist import drop_ctx
+            if drop_ctx.enabled:
+                drop_ctx.begin_step(self._kd_step, kd_offset, bs)
+                self._kd_step += 1
         if bs < full_bs:
             lr_batch = list_mult(lr_batch, bs / full_bs)
         opt = self.optimizer

@@ -39,8 +39,9 @@ SIGNATURES = {
     'nnl_prof_collect': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
     'nnl_embdotbias_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int, f32, f32,
                                      c_p, c_p]),
+    'nnl_embdotbias_bwd_workspace_bytes': (sz, [i64]),
     'nnl_embdotbias_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int,
-                                     f32, f32, c_p]),
+                                     f32, f32, c_p, sz, c_p]),
     'nnl_conv2d_fwd_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_dgrad_workspace_bytes': (sz, [C.POINTER(ConvGeom)]),
     'nnl_conv2d_tile_counters': (i64, []),
@@ -67,7 +68,8 @@ SIGNATURES = {
     'nnl_nms': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, i64, f32, c_p, c_p, c_p, c_p, c_p, sz, c_p]),
     'nnl_tab_renorm': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, f32, c_p, c_p]),
     'nnl_tab_gather_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, c_p]),
-    'nnl_tab_scatter_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i32, i32, i32, i32, c_p]),
+    'nnl_tab_scatter_bwd_workspace_bytes': (sz, [i64, i32]),
+    'nnl_tab_scatter_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, sz, c_p]),
     'nnl_retina_loss_workspace_bytes': (sz, [i64, i64]),
     'nnl_retina_loss_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, f32, f32, f32, c_p, sz, c_p]),
     'nnl_retina_loss_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, f32, f32, f32, c_p]),
@@ -77,7 +79,8 @@ SIGNATURES = {
     'nnl_lstm_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_lstm_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_embedding_rowmask_fwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, c_p, c_p]),
-    'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p]),
+    'nnl_embedding_rowmask_bwd_workspace_bytes': (sz, [i64]),
+    'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p, sz, c_p]),
     'nnl_softmax_ce_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p, c_p]),
     'nnl_softmax_ce_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p]),
     'nnl_optim_chunk_elems': (i64, []),

@@ -5,7 +5,7 @@
 // Layout: a 16-lane sub-group of a wave owns one sample (4 samples per 64-lane wave); lanes stride the
 // embedding dimension so each sub-group reads its two rows as contiguous 64-B segments, and the dot
 // product is reduced with 4 xor-shuffles inside the sub-group (no LDS).
-#include "nnl_common.h"
+#include "scatter_det.h"
 
 namespace {
 
@@ -81,6 +81,23 @@ __global__ __launch_bounds__(kBlock) void embdotbias_bwd_kernel(
   }
 }
 
+// g[b] = d loss / d (pre-sigmoid score) of sample b (0 for a sample with an out-of-range index)
+__global__ void embdot_g_kernel(const int64_t* __restrict__ x, const float* __restrict__ z, const float* __restrict__ dy,
+                                float* __restrict__ g, int64_t n, int64_t n_user, int64_t n_item, int has_range, float lo, float hi) {
+  for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < n; b += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t u = x[2 * b], it = x[2 * b + 1];
+    float v = 0.f;
+    if (!((u < 0) | (u >= n_user) | (it < 0) | (it >= n_item))) {
+      v = dy[b];
+      if (has_range) {
+        const float s = 1.f / (1.f + expf(-z[b]));
+        v *= (hi - lo) * s * (1.f - s);
+      }
+    }
+    g[b] = v;
+  }
+}
+
 int grid_for(int64_t n) {
   int64_t blocks = nnl_cdiv(n, kBlock / kSub);
   if (blocks > 2048) blocks = 2048;
@@ -105,10 +122,14 @@ extern "C" int nnl_embdotbias_fwd(const int64_t* x, const float* U, const float*
   return NNL_OK;
 }
 
+extern "C" size_t nnl_embdotbias_bwd_workspace_bytes(int64_t n) {
+  return n > 0 ? nnl_det::order_bytes(n, 2) + (size_t)n * sizeof(float) : 0;
+}
+
 extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float* M, const float* z,
                                   const float* dy, float* dU, float* dM, float* dbu, float* dbi,
                                   int64_t n, int64_t n_user, int64_t n_item, int64_t D, int has_range,
-                                  float lo, float hi, void* stream) {
+                                  float lo, float hi, void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(n >= 0 && n_user > 0 && n_item > 0 && D > 0 && D < (1 << 30), "embdotbias_bwd: bad sizes");
   NNL_CHECK_ARG(dU && dM && dbu && dbi, "embdotbias_bwd: null output");
   hipStream_t s = (hipStream_t)stream;
@@ -119,6 +140,30 @@ extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float*
   if (n == 0) return NNL_OK;
   NNL_CHECK_ARG(x && U && M && dy && (z || !has_range), "embdotbias_bwd: null pointer");
   NnlProfScope prof(NNL_PROF_EMBDOT, s, (double)n * (16 + 16.0 * D + 8 + 8));
+  if (nnl_det::use_det(n, workspace) && workspace_bytes >= nnl_embdotbias_bwd_workspace_bytes(n)) {
+    // deterministic: samples of a table row are added in sample order (scatter_det.h)
+    int* order = (int*)workspace;
+    float* g = (float*)((char*)workspace + nnl_det::order_bytes(n, 2));
+    hipLaunchKernelGGL(embdot_g_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, z, dy, g, n, n_user, n_item, has_range, lo, hi);
+    NNL_CHECK_LAUNCH();
+    int st = nnl_det::sort_rows(x, 2, n, 2, order, s);
+    if (st) return st;
+    nnl_det::SegSumParams q{};
+    q.idx = x; q.idx_stride = 2; q.n = (int)n; q.scale_i = g; q.scale_i_stride = 0; q.skip_row = -1;
+    q.srcrow = x; q.srcrow_stride = 2;
+    // dU[u] = sum g * M[item];  dM[item] = sum g * U[u]: the "column" of a launch is selected by offsetting idx / order
+    q.order = order; q.card = n_user; q.D = (int)D; q.dst = dU; q.src = M; q.ld = D; q.srcrow_col = 1;
+    if ((st = nnl_det::segsum(q, 1, s))) return st;
+    nnl_det::SegSumParams r = q;
+    r.idx = x + 1; r.order = order + n; r.card = n_item; r.dst = dM; r.src = U; r.srcrow = x; r.srcrow_col = 0;
+    if ((st = nnl_det::segsum(r, 1, s))) return st;
+    // biases: dst[row] = sum g
+    nnl_det::SegSumParams b = q;
+    b.D = 1; b.dst = dbu; b.src = g; b.ld = 1; b.srcrow = nullptr; b.scale_i = nullptr;
+    if ((st = nnl_det::segsum(b, 1, s))) return st;
+    b.idx = x + 1; b.order = order + n; b.card = n_item; b.dst = dbi;
+    return nnl_det::segsum(b, 1, s);
+  }
   hipLaunchKernelGGL(embdotbias_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, U, M, z, dy, dU, dM,
                      dbu, dbi, n, n_user, n_item, (int)D, has_range, lo, hi);
   NNL_CHECK_LAUNCH();

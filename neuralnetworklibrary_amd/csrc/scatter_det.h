@@ -1,0 +1,102 @@
+// Deterministic scatter-add of sample rows into table rows (dense embedding gradients): the replacement of fp32 atomicAdd in
+// embdotbias_bwd / tab_scatter_bwd / embedding_rowmask_bwd.  torch's embedding_dense_backward on the CPU — what the reference's
+// `nn.Embedding(sparse=False)` runs (CollabFiltering.py:196-204, General/Layers.py:63-76, Text.py:465-475) — adds the samples of
+// a row in sample order; atomics add them in arrival order, so gradients differed bit-wise from run to run whenever an index
+// repeated, while conv / LSTM / BN are bitwise reproducible.  Two kernels:
+//   1. rank sort: order[c][rank] = sample i, rank = #{j : key_j < key_i or (key_j == key_i and j < i)} — keys staged through LDS
+//      tiles, n^2 integer compares (n = 8192: 67 M, a few microseconds on 256 CUs), exact and stable by construction;
+//   2. segment sum: one wave per sorted position; the wave that sits on the first sample of a row walks that row's samples in
+//      order, lanes across the row's elements, and STORES the sum (rows nobody touched keep the zero of the memset).
+#pragma once
+#include "nnl_common.h"
+
+namespace nnl_det {
+
+constexpr int kSortBlock = 256;
+constexpr int kSortTile = 2048;
+constexpr long kMaxSamples = 32768;      // above this the O(n^2) ranking stops paying for itself: callers keep the atomic kernels
+
+static __global__ __launch_bounds__(kSortBlock) void rank_sort_kernel(const int64_t* __restrict__ idx, long stride, int n,
+                                                                int* __restrict__ order) {
+  __shared__ int64_t tile[kSortTile];
+  const int c = blockIdx.y;
+  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  const int64_t ki = i < n ? idx[(long)i * stride + c] : 0;
+  int rank = 0;
+  for (int t0 = 0; t0 < n; t0 += kSortTile) {
+    const int tn = min(kSortTile, n - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += kSortBlock) tile[j] = idx[(long)(t0 + j) * stride + c];
+    __syncthreads();
+    if (i < n) {
+      // keys before sample i in the tile count on "<=", keys after it on "<": ties keep sample order
+      const int split = min(max(i - t0, 0), tn);
+      for (int j = 0; j < split; ++j) rank += tile[j] <= ki;
+      for (int j = split; j < tn; ++j) rank += tile[j] < ki;
+    }
+  }
+  if (i < n) order[(long)c * n + rank] = i;
+}
+
+struct SegSumParams {
+  const int64_t* idx; long idx_stride;            // row of sample i in column c: idx[i * idx_stride + c]
+  const int* order;                               // [ncols][n] from rank_sort_kernel
+  int n;
+  const int32_t* card_arr; long card;             // rows of column c are valid in [0, card)      (array per column, or the scalar)
+  const int32_t* dim_arr; int D;                  // elements per row
+  const int32_t* coff_arr; int coff;              // first source column of this table's window
+  const int64_t* dst_off_arr; long dst_off;       // dst + dst_off + row * D + d
+  float* dst;
+  const float* src; long ld;                      // source row r: src + r * ld + coff
+  const int64_t* srcrow; long srcrow_stride; int srcrow_col;    // null: r = sample index; else r = srcrow[i * stride + col]
+  const float* scale_i; long scale_i_stride;      // null: 1; else scale_i[c * scale_i_stride + i]
+  const float* scale_row;                         // null: 1; else scale_row[row]
+  long skip_row;                                  // a row that receives no gradient (padding_idx), or -1
+};
+
+static __global__ __launch_bounds__(256) void segsum_kernel(SegSumParams p) {
+  const int c = blockIdx.y, lane = threadIdx.x & 63;
+  const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pos >= p.n) return;
+  const int* ord = p.order + (long)c * p.n;
+  const int64_t row = p.idx[(long)ord[pos] * p.idx_stride + c];
+  const long card = p.card_arr ? p.card_arr[c] : p.card;
+  if (row < 0 || row >= card || row == p.skip_row) return;
+  if (pos > 0 && p.idx[(long)ord[pos - 1] * p.idx_stride + c] == row) return;        // not the first sample of its row
+  const int D = p.dim_arr ? p.dim_arr[c] : p.D;
+  const int coff = p.coff_arr ? p.coff_arr[c] : p.coff;
+  float* out = p.dst + (p.dst_off_arr ? p.dst_off_arr[c] : p.dst_off) + row * D;
+  const float srow = p.scale_row ? p.scale_row[row] : 1.f;
+  for (int d0 = 0; d0 < D; d0 += 64) {
+    const int d = d0 + lane;
+    float acc = 0.f;
+    for (int q = pos; q < p.n; ++q) {
+      const int i = ord[q];
+      if (p.idx[(long)i * p.idx_stride + c] != row) break;
+      const long r = p.srcrow ? p.srcrow[(long)i * p.srcrow_stride + p.srcrow_col] : i;
+      float sc = srow;
+      if (p.scale_i) sc *= p.scale_i[(long)c * p.scale_i_stride + i];
+      if (d < D) acc += p.src[r * p.ld + coff + d] * sc;
+    }
+    if (d < D) out[d] = acc;
+  }
+}
+
+static inline size_t order_bytes(long n, int ncols) { return (size_t)n * ncols * sizeof(int); }
+
+static inline int sort_rows(const int64_t* idx, long stride, long n, int ncols, int* order, hipStream_t s) {
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)nnl_cdiv(n, kSortBlock), ncols), dim3(kSortBlock), 0, s, idx, stride, (int)n, order);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+static inline int segsum(const SegSumParams& p, int ncols, hipStream_t s) {
+  hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)nnl_cdiv(p.n, 4), ncols), dim3(256), 0, s, p);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+// deterministic by default; NNL_SCATTER_ATOMIC=1 selects the fp32-atomicAdd kernels (A/B and very large minibatches)
+static inline bool use_det(long n, const void* workspace) { return workspace != nullptr && n <= kMaxSamples && NNL_ENV_INT("NNL_SCATTER_ATOMIC", 0) == 0; }
+
+}  // namespace nnl_det

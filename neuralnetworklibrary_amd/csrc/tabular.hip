@@ -5,7 +5,7 @@
 //
 // HBM/gather-bound and tiny: per sample 8*ncat B of indices + 4*sum(d_j) B gathered + 4*D_out B written.
 // Descriptors live in device memory: tables[j] (pointer), card[j], dim[j], col_off[j] (first output column).
-#include "nnl_common.h"
+#include "scatter_det.h"
 
 namespace {
 
@@ -104,6 +104,17 @@ __global__ void tab_scatter_kernel(const int64_t* __restrict__ xcat, const int32
   }
 }
 
+__global__ void tab_dcont_kernel(const float* __restrict__ dout, const float* __restrict__ cont_mask, float* __restrict__ dcont,
+                                 long bs, int cat_width, int n_cont, int ld_out) {
+  const long total = bs * n_cont;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / n_cont;
+    const int e = (int)(i - b * n_cont);
+    const float g = dout[b * ld_out + cat_width + e];
+    dcont[i] = cont_mask ? g * cont_mask[i] : g;
+  }
+}
+
 int grid_for(long n) {
   long b = nnl_cdiv(n, kBlock);
   if (b > 4096) b = 4096;
@@ -147,11 +158,15 @@ extern "C" int nnl_tab_gather_fwd(const int64_t* xcat, const float* const* table
   return NNL_OK;
 }
 
+extern "C" size_t nnl_tab_scatter_bwd_workspace_bytes(int64_t bs, int32_t ncat) {
+  return (bs > 0 && ncat > 0) ? nnl_det::order_bytes(bs, ncat) : 0;
+}
+
 extern "C" int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, const int32_t* dim, const int32_t* col_off,
                                    const int32_t* col_table, const int64_t* grad_off, const float* row_mask,
                                    const float* cont_mask, const float* dout, float* dtab_flat, int64_t dtab_elems,
                                    float* dcont, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out,
-                                   void* stream) {
+                                   void* workspace, size_t workspace_bytes, void* stream) {
   NNL_CHECK_ARG(bs >= 0 && ncat >= 0 && cat_width >= 0 && n_cont >= 0 && ld_out >= cat_width + n_cont && dtab_elems >= 0,
                 "tab_scatter_bwd: bad sizes");
   hipStream_t s = (hipStream_t)stream;
@@ -160,6 +175,24 @@ extern "C" int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, con
   NNL_CHECK_ARG(dout && (ncat == 0 || (xcat && card && dim && col_off && col_table && grad_off && dtab_flat)),
                 "tab_scatter_bwd: null pointer");
   NnlProfScope prof(NNL_PROF_TABULAR, s, (double)bs * (8.0 * ncat + 8.0 * (cat_width + n_cont)));
+  if (ncat > 0 && nnl_det::use_det(bs, workspace) && workspace_bytes >= nnl_tab_scatter_bwd_workspace_bytes(bs, ncat)) {
+    // deterministic: per column, the samples of a table row are added in sample order (scatter_det.h); one sort launch and one
+    // segment-sum launch cover all ncat columns
+    int* order = (int*)workspace;
+    int st = nnl_det::sort_rows(xcat, ncat, bs, ncat, order, s);
+    if (st) return st;
+    nnl_det::SegSumParams q{};
+    q.idx = xcat; q.idx_stride = ncat; q.order = order; q.n = (int)bs;
+    q.card_arr = card; q.dim_arr = dim; q.coff_arr = col_off; q.dst_off_arr = grad_off; q.dst = dtab_flat;
+    q.src = dout; q.ld = ld_out; q.scale_i = row_mask; q.scale_i_stride = bs; q.skip_row = -1;
+    if ((st = nnl_det::segsum(q, ncat, s))) return st;
+    if (dcont && n_cont > 0) {
+      hipLaunchKernelGGL(tab_dcont_kernel, dim3(grid_for(bs * n_cont)), dim3(kBlock), 0, s, dout, cont_mask, dcont, (long)bs, cat_width,
+                         n_cont, ld_out);
+      NNL_CHECK_LAUNCH();
+    }
+    return NNL_OK;
+  }
   hipLaunchKernelGGL(tab_scatter_kernel, dim3(grid_for(bs * (cat_width + n_cont))), dim3(kBlock), 0, s, xcat, card, dim, col_off,
                      col_table, grad_off, row_mask, cont_mask, dout, dtab_flat, dcont, (long)bs, ncat, cat_width, n_cont, ld_out);
   NNL_CHECK_LAUNCH();

@@ -5,7 +5,7 @@
 //    one online-softmax pass per row forward (max and sum-exp together), one pass backward.
 // Both are HBM-bound: CE reads 4*V B per token forward and reads+writes 8*V B backward (V = 47 343: 848 MB of
 // logits per 4 480-token step).
-#include "nnl_common.h"
+#include "scatter_det.h"
 
 namespace {
 
@@ -148,8 +148,11 @@ extern "C" int nnl_embedding_rowmask_fwd(const int64_t* x, const float* W, const
   return NNL_OK;
 }
 
+extern "C" size_t nnl_embedding_rowmask_bwd_workspace_bytes(int64_t n) { return n > 0 ? nnl_det::order_bytes(n, 1) : 0; }
+
 extern "C" int nnl_embedding_rowmask_bwd(const int64_t* x, const float* rowmask, const float* dout, float* dW, int64_t n,
-                                         int64_t V, int64_t D, int64_t padding_idx, void* stream) {
+                                         int64_t V, int64_t D, int64_t padding_idx, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   NNL_CHECK_ARG(n >= 0 && V > 0 && D > 0 && D < (1 << 24), "embedding_rowmask_bwd: bad sizes");
   NNL_CHECK_ARG(dW, "embedding_rowmask_bwd: null output");
   hipStream_t s = (hipStream_t)stream;
@@ -157,6 +160,15 @@ extern "C" int nnl_embedding_rowmask_bwd(const int64_t* x, const float* rowmask,
   if (n == 0) return NNL_OK;
   NNL_CHECK_ARG(x && dout, "embedding_rowmask_bwd: null pointer");
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, (double)n * (8 + 8.0 * D) + 4.0 * V * D);
+  if (nnl_det::use_det(n, workspace) && workspace_bytes >= nnl_embedding_rowmask_bwd_workspace_bytes(n)) {
+    int* order = (int*)workspace;                 // deterministic: the tokens of a vocabulary row are added in token order
+    int st = nnl_det::sort_rows(x, 1, n, 1, order, s);
+    if (st) return st;
+    nnl_det::SegSumParams q{};
+    q.idx = x; q.idx_stride = 1; q.order = order; q.n = (int)n; q.card = V; q.D = (int)D; q.dst = dW; q.src = dout; q.ld = D;
+    q.scale_row = rowmask; q.skip_row = padding_idx;
+    return nnl_det::segsum(q, 1, s);
+  }
   hipLaunchKernelGGL(emb_rowmask_bwd_kernel, dim3(grid_for(n * D)), dim3(kBlock), 0, s, x, rowmask, dout, dW, (long)n, (int)V, (int)D,
                      (long)padding_idx);
   NNL_CHECK_LAUNCH();

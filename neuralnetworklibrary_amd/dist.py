@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 __all__ = ['init_from_env', 'GradSync', 'ShardedBatches', 'shard_bounds', 'enable_sync_bn', 'enable_sync_renorm', 'world_size',
-           'rank']
+           'rank', 'drop_ctx', 'keyed_mask', 'KeyedDropout']
 
 
 def world_size():
@@ -279,3 +279,76 @@ def enable_sync_renorm(model, capacity, group=None, comm=None):
         if hasattr(m, 'embeddings') and hasattr(m, '_plan'):
             m.nnl_dp = (group, comm or DistComm, int(capacity))
     return model
+
+
+# ---- dropout masks keyed by (seed, step, call, GLOBAL sample index) ------------------------------------------------------
+# The reference draws every dropout mask from torch's global RNG stream (General/Layers.py:74-76, Text.py:443-475, nn.Dropout in
+# the heads).  Under data parallelism each rank owns a different stream, so (a) the per-sample masks of a rank's shard are not
+# the masks the single-process run gives those samples and (b) masks over PARAMETERS (the LSTM weight drop [4H, H], the
+# vocabulary-row mask [V, 1]) differ between ranks — every replica then differentiates a different network.  With
+# `Learner.use_keyed_dropout(seed)` every mask element is a pure function of (seed, training step, index of the mask request
+# within the step, element index), the element index being taken in the GLOBAL minibatch for per-sample masks: an N-rank run with
+# dropout ON reproduces the 1-rank run on the same global minibatches.  Integer hashing only
+# (splitmix64 finaliser in wrapping int64 arithmetic): bit-identical on every device and torch version.
+class _DropCtx:
+    def __init__(self):
+        self.enabled, self.seed, self.step, self.calls, self.offset, self.global_rows = False, 0, 0, 0, 0, None
+
+    def begin_step(self, step, offset=0, global_rows=None):
+        "called by Learner.train1minibatch: `offset` = index of this rank's first row in the global minibatch of `global_rows` rows"
+        self.step, self.calls, self.offset, self.global_rows = int(step), 0, int(offset), global_rows
+
+
+drop_ctx = _DropCtx()
+
+
+def _s64(v):
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _mix(x):
+    "splitmix64 finaliser on an int64 tensor (logical shifts emulated by masking the sign extension)"
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * _s64(0xBF58476D1CE4E5B9)
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * _s64(0x94D049BB133111EB)
+    return x ^ ((x >> 31) & ((1 << 33) - 1))
+
+
+def keyed_mask(shape, p, device, sample_dim=None):
+    """Bernoulli(1 - p) / (1 - p) mask of `shape` under the keyed scheme, or None when it is not enabled (the caller then draws
+    from torch's stream as the reference does).  sample_dim: the dimension that indexes the samples of the minibatch (None: a
+    parameter-shaped mask, identical on every rank)."""
+    c = drop_ctx
+    if not c.enabled:
+        return None
+    c.calls += 1
+    shape = tuple(int(v) for v in shape)
+    gshape = list(shape)
+    idx = torch.zeros(shape, dtype=torch.int64, device=device)
+    if sample_dim is not None and c.global_rows is not None:
+        gshape[sample_dim] = max(int(c.global_rows), shape[sample_dim] + c.offset)
+    stride = 1
+    for d in reversed(range(len(shape))):
+        ar = torch.arange(shape[d], dtype=torch.int64, device=device)
+        if d == sample_dim:
+            ar = ar + c.offset
+        idx = idx + (ar * stride).view([-1 if k == d else 1 for k in range(len(shape))])
+        stride *= gshape[d]
+    key = _s64(c.seed * 0x9E3779B97F4A7C15 + c.step * 0xD1B54A32D192ED03 + c.calls * 0x8CB92BA72F3D8DD7)
+    h = _mix(_mix(idx + key) + _s64(0x9E3779B97F4A7C15))
+    u = ((h >> 40) & 0xFFFFFF).to(torch.float32) * (1.0 / (1 << 24))
+    return (u >= p).to(torch.float32) * (1.0 / (1.0 - p)) if p < 1 else torch.zeros(shape, device=device)
+
+
+class KeyedDropout(torch.nn.Dropout):
+    """nn.Dropout whose mask comes from `keyed_mask` (rows = samples) when the keyed scheme is on; exactly nn.Dropout otherwise.
+    sample_dim: which dimension of the input indexes the samples (None: parameter-shaped input, e.g. the LSTM weight drop)."""
+
+    def __init__(self, p=0.5, sample_dim=0):
+        super().__init__(p)
+        self.sample_dim = sample_dim
+
+    def forward(self, x):
+        if self.training and self.p > 0 and drop_ctx.enabled:
+            return x * keyed_mask(x.shape, self.p, x.device, self.sample_dim)
+        return super().forward(x)

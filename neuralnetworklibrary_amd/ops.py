@@ -73,9 +73,11 @@ class _EmbDotBias(torch.autograd.Function):
         dU, dM = torch.empty_like(U), torch.empty_like(M)
         dbu = torch.empty(U.shape[0], 1, dtype=torch.float32, device=U.device)
         dbi = torch.empty(M.shape[0], 1, dtype=torch.float32, device=U.device)
+        wsb = int(lib.nnl_embdotbias_bwd_workspace_bytes(x.shape[0]))          # sample-order (deterministic) scatter-add
+        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=U.device)
         check(lib.nnl_embdotbias_bwd(ptr(x), ptr(U), ptr(M), ptr(z), ptr(dy), ptr(dU), ptr(dM), ptr(dbu), ptr(dbi),
                                      x.shape[0], U.shape[0], M.shape[0], U.shape[1], int(has_range), lo, hi,
-                                     stream()))
+                                     ptr(ws), wsb, stream()))
         return None, dU, dM, dbu, dbi, None, None
 
 
@@ -740,9 +742,11 @@ class _TabEmbedConcat(torch.autograd.Function):
         bs = xcat.shape[0]
         flat = torch.empty(max(plan.grad_elems, 1), dtype=torch.float32, device=dout.device)
         dcont = torch.empty(bs, n_cont, dtype=torch.float32, device=dout.device) if (n_cont and ctx.needs_input_grad[1]) else None
+        wsb = int(lib.nnl_tab_scatter_bwd_workspace_bytes(bs, plan.ncat))            # sample-order (deterministic) scatter-add
+        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dout.device)
         check(lib.nnl_tab_scatter_bwd(ptr(xcat), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off), ptr(plan.col_table),
                                       ptr(plan.grad_off), ptr(row_mask), ptr(cont_mask), ptr(dout), ptr(flat), plan.grad_elems,
-                                      ptr(dcont), bs, plan.ncat, plan.cat_width, n_cont, dout.shape[1], stream()))
+                                      ptr(dcont), bs, plan.ncat, plan.cat_width, n_cont, dout.shape[1], ptr(ws), wsb, stream()))
         grads, o = [], 0
         for n, shp in zip(plan.grad_sizes, plan.shapes):
             grads.append(flat[o:o + n].view(shp))

@@ -113,7 +113,9 @@ class _EmbeddingRowMask(torch.autograd.Function):
         V, D, pad = ctx.meta
         dout = _f32c(dout)
         dW = torch.empty(V, D, dtype=torch.float32, device=dout.device)
-        check(lib.nnl_embedding_rowmask_bwd(ptr(xi), ptr(rm), ptr(dout), ptr(dW), xi.numel(), V, D, pad, stream()))
+        wsb = int(lib.nnl_embedding_rowmask_bwd_workspace_bytes(xi.numel()))         # sample-order (deterministic) scatter-add
+        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dout.device)
+        check(lib.nnl_embedding_rowmask_bwd(ptr(xi), ptr(rm), ptr(dout), ptr(dW), xi.numel(), V, D, pad, ptr(ws), wsb, stream()))
         return None, dW, None, None
 
 

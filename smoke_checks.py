@@ -1,5 +1,6 @@
-"""Small GPU-vs-oracle checks used by __graft_entry__.smoke(): one tiny forward+backward of every hot-path head on
-the HIP kernels (through the C ABI), compared with the CPU oracle (imported here as the CHECKER only)."""
+"""TEST INFRASTRUCTURE (lives next to __graft_entry__.py, outside the product package).  Small GPU-vs-oracle checks used by
+__graft_entry__.smoke(): one tiny forward+backward of every hot-path head on the HIP kernels (through the C ABI), compared with
+the CPU oracle (imported here as the CHECKER only)."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -14,7 +15,7 @@ def _close(a, b, rtol, atol, what):
 
 def check_collab(device):
     from oracle import reference_math as RM
-    from . import ops
+    from neuralnetworklibrary_amd import ops
     g = torch.Generator().manual_seed(0)
     n, nu, ni, D = 64, 943, 1682, 30
     x = torch.stack([torch.randint(0, nu, (n,), generator=g), torch.randint(0, ni, (n,), generator=g)], 1)
@@ -34,7 +35,7 @@ def check_resnet_block(device):
     """conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> +downsample(x) -> ReLU, stride 2 (conv fwd/dgrad/wgrad + fused BN)."""
     from oracle import reference_nets as RN
     from oracle import synth
-    from .Applications.VisionModels import retinanet as PN
+    from neuralnetworklibrary_amd.Applications.VisionModels import retinanet as PN
     ds_p = PN._Downsample(PN.HipConv2d(16, 32, kernel_size=1, stride=2, bias=False), nn.BatchNorm2d(32))
     ds_o = nn.Sequential(nn.Conv2d(16, 32, 1, stride=2, bias=False), nn.BatchNorm2d(32))
     prod, orac = PN.BasicBlock(16, 32, 2, ds_p), RN.BasicBlock(16, 32, 2, ds_o)
@@ -52,7 +53,7 @@ def check_resnet_block(device):
 def check_tabular(device):
     from oracle import reference_nets as RN
     from oracle import synth
-    from .Applications.StructuredData import StructuredDataNet
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
     cards, n_cont, bs = [20, 5, 4, 13], 3, 32
     dims = [RN.embedding_dim(c) for c in cards]
     prod = StructuredDataNet('cont', 4, n_cont, [{i: i for i in range(c)} for c in cards], [32, 16, 1], output_range=[5, 12])
@@ -71,7 +72,7 @@ def check_tabular(device):
 
 def check_retina_loss(device):
     from oracle import reference_math as RM
-    from . import ops
+    from neuralnetworklibrary_amd import ops
     rs = np.random.RandomState(2)
     anchors = RM.anchors_for(64, 64)
     A, K, bs = len(anchors), 5, 2
@@ -91,7 +92,7 @@ def check_retina_loss(device):
 def check_lstm_lm(device):
     from oracle import reference_text as RT
     from oracle import synth
-    from .Applications.Text import LanguageModelNet, RegSeqCrossEntropyLoss, _Vocab
+    from neuralnetworklibrary_amd.Applications.Text import LanguageModelNet, RegSeqCrossEntropyLoss, _Vocab
     V, bs, seq = 40, 4, 6
     stoi = {('t%d' % i): i for i in range(V)}
     stoi['_pad_'] = 1
@@ -113,7 +114,7 @@ CHECKS = [check_collab, check_resnet_block, check_tabular, check_retina_loss, ch
 
 
 def run_all(device='cuda:0'):
-    from . import ops
+    from neuralnetworklibrary_amd import ops
     for c in CHECKS:
         c(device)
         print('  smoke check passed:', c.__name__)

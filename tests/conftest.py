@@ -58,3 +58,8 @@ def _nnl_env_switches_fresh():
     yield
     if lib is not None:
         lib.nnl_reload_env()
+    try:                                                  # Learner.use_keyed_dropout() flips a process-wide switch
+        from neuralnetworklibrary_amd.dist import drop_ctx
+        drop_ctx.enabled = False
+    except Exception:
+        pass

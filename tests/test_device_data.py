@@ -83,3 +83,57 @@ def test_language_model_loader_device_resident_yields_the_same_windows():
     for (xa, ya), (xb, yb) in zip(a, b):
         assert torch.equal(xa, xb) and torch.equal(ya, yb) and xb.is_contiguous()
         assert torch.equal(xb[:, 1:], yb[:, :-1])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_device_resident_loaders_equal_the_dataloader_path_on_the_gpu():
+    """VERDICT r1 (row f3): on `cuda`, the device-resident pipelines hand the model exactly the minibatches the reference's
+    DataLoader + collater + to_cuda path does (collab, structured data, language model), and the Learner computes the same
+    validation loss through either."""
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterDataObj, CollabFilterNet
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataObj, StructuredDataset
+    from neuralnetworklibrary_amd.Applications.Text import LanguageModelDataLoader
+    from neuralnetworklibrary_amd.General.Core import set_default_device, to_cuda
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device('cuda')
+    Learner.verbose = False
+    rs = np.random.RandomState(0)
+    n = 400
+    df = pd.DataFrame({'u': rs.randint(0, 30, n), 'm': rs.randint(0, 20, n), 'r': rs.randint(1, 6, n).astype('float32')})
+    labels = [{u: i for i, u in enumerate(sorted(df.u.unique()))}, {m: i for i, m in enumerate(sorted(df.m.unique()))}]
+    host = CollabFilterDataObj(df[:300], df[300:], 'u', 'm', 'r', labels, bs=64, num_workers=0)
+    dev = CollabFilterDataObj(df[:300], df[300:], 'u', 'm', 'r', labels, bs=64, num_workers=0, device_resident=True)
+    nb = 0
+    for (xh, yh), (xd, yd) in zip(host.val_dl, dev.val_dl):
+        assert xd.is_cuda and yd.is_cuda and torch.equal(to_cuda(xh), xd) and torch.equal(to_cuda(yh), yd)
+        nb += 1
+    assert nb == 2 and len(dev.train_dl) == len(host.train_dl)
+    torch.manual_seed(0)
+    net = CollabFilterNet(len(labels[0]), len(labels[1]), 8, [0.8, 5.2])
+    lh = Learner('/tmp/nnl_test_dd', host, net, optimizer='Adam').evaluate('val')[0]
+    ld = Learner('/tmp/nnl_test_dd', dev, net, optimizer='Adam').evaluate('val')[0]
+    assert lh == ld
+    learner = Learner('/tmp/nnl_test_dd', dev, net, optimizer='Adam')
+    learner.fit(1e-2, 1, wd=1e-4)                                     # an epoch through the device-resident loader trains
+    assert learner.evaluate('val')[0] < ld
+
+    xcat = pd.DataFrame(rs.randint(0, 5, (200, 3))); xcont = pd.DataFrame(rs.standard_normal((200, 2)).astype('float32'))
+    yv = rs.rand(200).astype('float32')
+    tr, va = StructuredDataset(xcat[:150], xcont[:150], yv[:150], 'cont'), StructuredDataset(xcat[150:], xcont[150:], yv[150:], 'cont')
+    hs = StructuredDataObj(tr, va, None, None, bs=32, num_workers=0)
+    ds = StructuredDataObj(tr, va, None, None, bs=32, num_workers=0, device_resident=True)
+    for ((ch, fh), yh), ((cd, fd), yd) in zip(hs.val_dl, ds.val_dl):
+        assert cd.is_cuda and torch.equal(to_cuda(ch), cd) and torch.equal(to_cuda(fh), fd) and torch.equal(to_cuda(yh), yd)
+
+    class DS:
+        texts = [list(range(i, i + 37)) for i in range(0, 300, 37)]
+        num_tokens = sum(len(t) for t in texts)
+
+    a = LanguageModelDataLoader(DS, bs=4, bptt=10, random=False)
+    b = LanguageModelDataLoader(DS, bs=4, bptt=10, random=False, device_resident=True)
+    for (xa, ya), (xb, yb) in zip(a, b):
+        assert xb.is_cuda and torch.equal(to_cuda(xa), xb) and torch.equal(to_cuda(ya), yb)
+    set_default_device('cpu')

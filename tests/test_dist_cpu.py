@@ -16,10 +16,13 @@ def _free_port():
     return p
 
 
-def _model(seed=0):
+def _model(seed=0, dropout=0.0):
     from neuralnetworklibrary_amd.General.Core import make_model_basic
+    from neuralnetworklibrary_amd.dist import KeyedDropout
     torch.manual_seed(seed)
-    net = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), nn.Linear(16, 16), nn.Tanh(), nn.Linear(16, 1), nn.Flatten(0))
+    drop = [KeyedDropout(dropout)] if dropout else []
+    net = nn.Sequential(nn.Linear(6, 16), nn.Tanh(), *drop, nn.Linear(16, 16), nn.Tanh(), *([KeyedDropout(dropout)] if dropout else []),
+                        nn.Linear(16, 1), nn.Flatten(0))
     return make_model_basic(net)
 
 
@@ -39,7 +42,7 @@ class _Data:
         self.train_dl, self.val_dl, self.bs = batches, batches, bs
 
 
-def _fit(rank, world, port, q, last=6, n_batches=5, hint=True):
+def _fit(rank, world, port, q, last=6, n_batches=5, hint=True, dropout=0.0):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist
     from neuralnetworklibrary_amd import dist as nd
@@ -55,8 +58,10 @@ def _fit(rank, world, port, q, last=6, n_batches=5, hint=True):
     if not hint:
         shard = list(shard)          # plain pre-cut batches: no dp_info -> the Learner agrees on the batch size by all-reduce
     data = _Data(shard, 8 // world)
-    net = _model()
+    net = _model(dropout=dropout)
     learner = Learner('/tmp/nnl_dist_test_%d_%d' % (world, rank), data, net, optimizer='Adam')
+    if dropout:
+        learner.use_keyed_dropout(seed=11)            # masks keyed by (seed, step, request, GLOBAL sample index)
     if world > 1:
         learner.distribute(bucket_mb=0.0005)          # tiny buckets: several collectives per step
         assert len(learner.grad_sync.buckets) > 1
@@ -99,6 +104,18 @@ def test_ragged_last_batch_unequal_and_ghost_shards(world, last, hint):
     _, w1 = _run(1, last=last, n_batches=3)
     _, wn = _run(world, last=last, n_batches=3, hint=hint)
     np.testing.assert_allclose(wn, w1, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('world,last', [(2, 8), (2, 7), (4, 6)])
+def test_dropout_on_two_ranks_reproduce_one_rank_with_keyed_masks(world, last):
+    """VERDICT r1 #8 / SURVEY §7 step 9: with `Learner.use_keyed_dropout` every dropout mask element is a function of (seed,
+    step, request, global sample index), so an N-rank run with dropout ON equals the 1-rank run on the same global minibatches
+    (equal, unequal and 1-row shards); with torch's per-process streams it could not."""
+    l1, w1 = _run(1, last=last, n_batches=3, dropout=0.3)
+    ln, wn = _run(world, last=last, n_batches=3, dropout=0.3)
+    np.testing.assert_allclose(wn, w1, rtol=2e-5, atol=2e-6)
+    l0, w0 = _run(1, last=last, n_batches=3, dropout=0.0)
+    assert np.abs(w1 - w0).max() > 1e-4                     # (the dropout really was on)
 
 
 def test_shard_bounds_cover_every_row_once():
