@@ -1,5 +1,6 @@
 """Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command) into
-profiles/r1_pmc_{fetch,write}_size_summary.csv and profiles/r1_traffic.json (read by bench.py as roofline.traffic).
+profiles/<tag>_pmc_{fetch,write}_size_summary.csv and profiles/<tag>_traffic.json (read by bench.py as roofline.traffic; tag = r2, or
+argv[3]).
 Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv>
 Units: rocprofv3 reports both counters in KB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their size
 (MI355X_MICROARCH.md, HBM section) and is doubled; WRITE_SIZE is exact."""
@@ -22,9 +23,9 @@ def load(path, name):
     return tot, n
 
 
-def main(fetch_csv, write_csv):
+def main(fetch_csv, write_csv, tag='r2'):
     out = {}
-    for name, path, fn in (('FETCH_SIZE', fetch_csv, 'r1_pmc_fetch_size_summary.csv'), ('WRITE_SIZE', write_csv, 'r1_pmc_write_size_summary.csv')):
+    for name, path, fn in (('FETCH_SIZE', fetch_csv, tag + '_pmc_fetch_size_summary.csv'), ('WRITE_SIZE', write_csv, tag + '_pmc_write_size_summary.csv')):
         tot, n = load(path, name)
         with open(os.path.join(ROOT, 'profiles', fn), 'w') as f:
             f.write('Kernel_Name,Launches,%s_total_KB,%s_KB_per_launch\n' % (name, name))
@@ -39,16 +40,17 @@ def main(fetch_csv, write_csv):
     write = sum(W[k] for k in W if is_conv(k)) * 1024.0
     js = {
         'kernel': 'igemm_taps_kernel / igemm_wgrad_kernel (+ their slab reduces and the dgrad weight transposes): every conv / linear launch of bench.py',
-        'command': 'rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline',
+        'command': 'rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none',
+        'bs': 64, 'sz': 224, 'gpus': 1,
         'fetch_size_bytes_per_launch_raw': fetch / launches,
         'fetch_correction': 'x2 (gfx950 FETCH_SIZE reports half of wide coalesced reads; MI355X_MICROARCH.md HBM)',
         'write_size_bytes_per_launch': write / launches,
         'traffic_bytes_per_launch': (2 * fetch + write) / launches,
         'note': 'memory-side (L2 miss) traffic incl. Infinity-Cache hits; per-launch average over %d igemm launches' % launches,
     }
-    json.dump(js, open(os.path.join(ROOT, 'profiles', 'r1_traffic.json'), 'w'), indent=1)
+    json.dump(js, open(os.path.join(ROOT, 'profiles', tag + '_traffic.json'), 'w'), indent=1)
     print(json.dumps(js, indent=1))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
