@@ -654,14 +654,17 @@ def worker(args):
     if world > 1:
         per = max(args.bs // world, 1)
         strong = {'global_batch': per * world, 'per_gpu_batch': per}
-        for tag, sync_bn in (('local_bn', False), ('sync_bn', True)):
+        for tag, sync_bn, graphs in (('local_bn', False, False), ('local_bn_hipgraph', False, True), ('sync_bn', True, False)):
             w2 = resnet34_workload(device, per, seed, world, args.sz, sync_bn=sync_bn)
-            d2 = clock.timed(w2.step, args.warmup, args.steps)
+            if graphs:
+                w2.learner.use_graphs(True)
+            d2 = clock.timed(w2.step, args.warmup + (3 if graphs else 0), args.steps)
             strong[tag] = {'ms_per_step': round(d2 / args.steps * 1e3, 3), 'value': round(per * world * args.steps / d2, 2)}
             del w2
             torch.cuda.empty_cache()
-        strong['note'] = ('local_bn: per-replica BatchNorm statistics (standard DDP); sync_bn: global-batch statistics = the single-GPU '
-                          "reference's numerics on the same global minibatch (SURVEY.md §8e)")
+        strong['note'] = ('local_bn: per-replica BatchNorm statistics (standard DDP); local_bn_hipgraph: the same with forward + backward '
+                          'replayed as one hipGraph per step (Learner.use_graphs; the all-reduces and the optimizer launch follow it); sync_bn: '
+                          "global-batch statistics = the single-GPU reference's numerics on the same global minibatch (SURVEY.md §8e)")
         out['strong'] = strong
     elif not args.no_sweep:
         # one GPU: the compute-side ceiling of strong scaling — the per-GPU step at 64/N images
@@ -670,8 +673,12 @@ def worker(args):
             w2 = resnet34_workload(device, bs, seed, 1, args.sz)
             d2 = clock.timed(w2.step, max(args.warmup, 3), args.steps)
             m2 = d2 / args.steps * 1e3
+            w2.learner.use_graphs(True)                 # the whole step replayed as one hipGraph: no per-launch host cost
+            d3 = clock.timed(w2.step, max(args.warmup, 3) + 3, args.steps)
+            m3 = d3 / args.steps * 1e3
             proxy['bs%d' % bs] = {'ms_per_step': round(m2, 3), 'images_per_s': round(bs * args.steps / d2, 1),
-                                  't64_over_t': round(ms / m2, 2), 'ideal': 64 // bs}
+                                  't64_over_t': round(ms / m2, 2), 'hipgraph_ms_per_step': round(m3, 3),
+                                  'hipgraph_t64_over_t': round(ms / m3, 2), 'ideal': 64 // bs}
             del w2
             torch.cuda.empty_cache()
         proxy['note'] = 't64_over_t at bs=64/N bounds the strong-scaling speed-up at N GPUs before any communication (target >= 6.5 at N=8)'

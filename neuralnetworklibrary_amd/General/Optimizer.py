@@ -81,9 +81,10 @@ class Optimizer(object):
         return lrs, decays
 
     def graph_capturable(self):
-        "True when step() is a fixed sequence of launches whose hyper-parameters are read from device memory"
+        """True when step() is a fixed sequence of launches whose hyper-parameters are read from device memory (data parallel: the
+        step itself stays outside the graph, after the eager all-reduces — Learner._GraphedStep)"""
         fused = self._fused_stepper()
-        return fused is not None and fused.uniform_hyper() and self.grad_sync is None
+        return fused is not None and fused.uniform_hyper()
 
     def prepare_capture(self):
         self._fused.prepare_capture()

@@ -135,6 +135,7 @@ class GradSync:
                 p._nnl_uses = [0]
                 self._use_counts.append(p._nnl_uses)
         self._active = False
+        self.capturing = False                          # Learner.use_graphs under DP: hooks fill the buckets, collectives run after the replay
         self.weight = 1.0
         self.direct_writes, self.steps = 0, 0           # gradients that arrived in place / backward passes (diagnostics)
 
@@ -178,11 +179,20 @@ class GradSync:
             b.views[pi].copy_(p.grad)
         b.ready[pi] = True
         b.pending -= 1
+        if self.capturing:
+            return
         # collectives are issued strictly in bucket order on every rank (a rank whose data did not reach some parameter must
         # not pair its bucket k with another rank's bucket j): launch the complete buckets at the head of the queue
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
             self._launch(self.buckets[self._next])
             self._next += 1
+
+    def reduce_all(self, weight=1.0):
+        """After the replay of a captured forward + backward (which filled every bucket): all-reduce all buckets now, in order."""
+        self._active, self.weight, self._next = True, float(weight), 0
+        for b in self.buckets:
+            b.pending, b.ready, b.handle, b.averaged = 0, [True] * len(b.params), None, False
+        self.finish()
 
     def finish(self):
         """Wait for every bucket, average, and point param.grad at the averaged bucket views.

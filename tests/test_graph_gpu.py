@@ -120,3 +120,60 @@ def test_resnet_classifier_graph_replay_trains_like_eager():
     lg, ng = run(True)
     assert ng == 1
     assert_close(lg, le, 1e-5, 1e-6, 'losses: graph replay vs eager')
+
+
+def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
+    """Learner.use_graphs() with a GradSync attached: the captured forward + backward fills the all-reduce buckets (in-place
+    wgrad writes and the hooks' copies are part of the graph), every replay is followed by the eager bucket all-reduces and the
+    fused optimizer launch.  Run here on one GPU with a one-rank RCCL group and NNL_DIST_FORCE_ALLREDUCE semantics, so the RCCL
+    calls really are issued: the replayed run must train like the eager data-parallel run and like the plain eager run."""
+    import os
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    forced = nd._FORCE_ALLREDUCE
+    nd._FORCE_ALLREDUCE = True
+    try:
+        N, S = 8, 64
+        g = torch.Generator().manual_seed(4)
+        batches = [(torch.randn(N, 3, S, S, generator=g).to(DEV), torch.randint(0, 2, (N,), generator=g).to(DEV)) for _ in range(3)]
+
+        class D:
+            sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
+            train_dl = val_dl = batches
+
+        def run(dp, graphs):
+            torch.manual_seed(0)
+            net = V.ImageClassificationNet(D, V.models.resnet18(), head=[[64], [0., 0.]])
+            learner = Learner('/tmp/nnl_graph_test', D, net, optimizer='SGD_Mom')
+            learner.init_optimizer(wd=1e-4)
+            if dp:
+                learner.distribute(equal_shards=True)
+            if graphs:
+                learner.use_graphs(True, warmup=2)
+            net.train()
+            losses = [learner.train1minibatch(*batches[i % 3], [1e-3, 2e-3, 5e-3], mom_batch=0.9) for i in range(9)]
+            ng = sum(gs.graph is not None for gs in learner._graphs.values())
+            return np.array(losses), [p.detach().cpu().numpy().copy() for p in net.parameters()], ng
+        l0, p0, _ = run(False, False)
+        l1, p1, n1 = run(True, False)
+        l2, p2, n2 = run(True, True)
+        assert n1 == 0 and n2 == 1
+        assert_close(l1, l0, 1e-5, 1e-6, 'eager DP vs eager')
+        assert_close(l2, l1, 1e-5, 1e-6, 'graph DP vs eager DP')
+        for a, b in zip(p2, p1):
+            assert_close(a, b, 1e-4, 1e-6, 'params')
+    finally:
+        nd._FORCE_ALLREDUCE = forced
+        if created:
+            dist.destroy_process_group()
