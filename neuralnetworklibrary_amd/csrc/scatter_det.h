@@ -5,8 +5,9 @@
 // repeated, while conv / LSTM / BN are bitwise reproducible.  Two kernels:
 //   1. rank sort: order[c][rank] = sample i, rank = #{j : key_j < key_i or (key_j == key_i and j < i)} — keys staged through LDS
 //      tiles, n^2 integer compares (n = 8192: 67 M, a few microseconds on 256 CUs), exact and stable by construction;
-//   2. segment sum: one wave per sorted position; the wave that sits on the first sample of a row walks that row's samples in
-//      order, lanes across the row's elements, and STORES the sum (rows nobody touched keep the zero of the memset).
+//   2. segment sum: one wave per sorted position; the wave that sits on the first sample of a row adds that row's samples — lanes
+//      across the row's elements and, for narrow rows, across sample slots that are combined by a fixed tree — and STORES the sum
+//      (rows nobody touched keep the zero of the memset).  Rows hit once or a few times are summed exactly in sample order.
 #pragma once
 #include "nnl_common.h"
 
@@ -67,18 +68,35 @@ static __global__ __launch_bounds__(256) void segsum_kernel(SegSumParams p) {
   const int coff = p.coff_arr ? p.coff_arr[c] : p.coff;
   float* out = p.dst + (p.dst_off_arr ? p.dst_off_arr[c] : p.dst_off) + row * D;
   const float srow = p.scale_row ? p.scale_row[row] : 1.f;
-  for (int d0 = 0; d0 < D; d0 += 64) {
-    const int d = d0 + lane;
+  // segment length (wave-uniform): the samples of this row sit at sorted positions [pos, pos + len)
+  int len = 1;                                        // found 64 positions at a time (ballot), not by a chain of dependent loads
+  for (int base = pos + 1; base < p.n; base += 64) {
+    const int q = base + lane;
+    const bool same = q < p.n && p.idx[(long)ord[q] * p.idx_stride + c] == row;
+    const unsigned long long m = __ballot(!same);
+    if (m != 0ull) { len += __ffsll((long long)m) - 1; break; }
+    len += 64;
+  }
+  // lanes = SL sample slots x DL element slots (DL = the power of two >= min(D, 64)): slot s adds samples pos+s, pos+s+SL, ...
+  // in that order, then the SL partial sums are added by a fixed xor tree — one order per (D, len), so the result is bitwise
+  // reproducible; a short row (len <= SL... in particular every row without a repeated index) is a plain in-order sum.  Narrow
+  // tables (the tabular embeddings: 2 - 8 elements, hundreds of samples per row at cardinality 4) get 8 - 32 samples in flight
+  // per wave instead of one.
+  int DL = 1;
+  while (DL < D && DL < 64) DL <<= 1;
+  const int SL = 64 / DL, s = lane / DL, dl = lane - s * DL;
+  for (int d0 = 0; d0 < D; d0 += DL) {
+    const int d = d0 + dl;
     float acc = 0.f;
-    for (int q = pos; q < p.n; ++q) {
-      const int i = ord[q];
-      if (p.idx[(long)i * p.idx_stride + c] != row) break;
+    for (int q = s; q < len; q += SL) {
+      const int i = ord[pos + q];
       const long r = p.srcrow ? p.srcrow[(long)i * p.srcrow_stride + p.srcrow_col] : i;
       float sc = srow;
       if (p.scale_i) sc *= p.scale_i[(long)c * p.scale_i_stride + i];
       if (d < D) acc += p.src[r * p.ld + coff + d] * sc;
     }
-    if (d < D) out[d] = acc;
+    for (int o = DL; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (s == 0 && d < D) out[d] = acc;
   }
 }
 
