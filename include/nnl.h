@@ -333,8 +333,10 @@ int nnl_embedding_rowmask_bwd(const int64_t* x, const float* rowmask, const floa
  * Backward: dlogits = (softmax - onehot) * (*grad_out) / rows. */
 int nnl_softmax_ce_fwd(const float* logits, const int64_t* target, float* lse, float* loss_rows, float* loss_mean,
                        int64_t rows, int64_t V, int32_t* err_flag, void* stream);
+/* ld_dlogits >= V: row stride of dlogits; columns [V, ld_dlogits) are written as zeros (a gradient buffer whose rows are already
+ * padded to the GEMM granularity saves the consumer an 848 MB pad copy at V = 47 343). */
 int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
-                       float* dlogits, int64_t rows, int64_t V, void* stream);
+                       float* dlogits, int64_t rows, int64_t V, int64_t ld_dlogits, void* stream);
 
 /* ---- K8: fused multi-tensor Optimizer.step ------------------------------------------------------------------------
  * Replaces Optimizer.step (General/Optimizer.py:58-70): decoupled weight decay X *= 1 - wd_g*lr_g (:60-67), global-norm

@@ -82,7 +82,7 @@ SIGNATURES = {
     'nnl_embedding_rowmask_bwd_workspace_bytes': (sz, [i64]),
     'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p, sz, c_p]),
     'nnl_softmax_ce_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p, c_p]),
-    'nnl_softmax_ce_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p]),
+    'nnl_softmax_ce_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p]),
     'nnl_optim_chunk_elems': (i64, []),
     'nnl_optim_step': (C.c_int, [c_p, c_p, c_p, i64, C.c_int, c_p, C.c_int, c_p, c_p]),
     'nnl_bn_workspace_bytes': (sz, [i64, i64]),

@@ -112,10 +112,10 @@ __global__ void mean_kernel(const float* __restrict__ v, float* __restrict__ out
 __global__ __launch_bounds__(kBlock) void softmax_ce_bwd_kernel(const float* __restrict__ logits,
                                                                  const int64_t* __restrict__ target,
                                                                  const float* __restrict__ lse, const float* __restrict__ gup,
-                                                                 float* __restrict__ dlogits, int V, long rows) {
+                                                                 float* __restrict__ dlogits, int V, long rows, long ld) {
   const long r = blockIdx.x;
   const float* __restrict__ row = logits + r * V;
-  float* __restrict__ drow = dlogits + r * V;
+  float* __restrict__ drow = dlogits + r * ld;
   const float l = lse[r];
   const float g = gup[0] / (float)rows;
   const int64_t tg = target[r];
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(kBlock) void softmax_ce_bwd_kernel(const float* __r
     if (v == tg) p -= 1.f;
     drow[v] = p * g;
   }
+  for (int v = V + threadIdx.x; v < ld; v += kBlock) drow[v] = 0.f;        // pad columns of a padded gradient buffer
 }
 
 int grid_for(long n) {
@@ -189,13 +190,13 @@ extern "C" int nnl_softmax_ce_fwd(const float* logits, const int64_t* target, fl
 }
 
 extern "C" int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
-                                  float* dlogits, int64_t rows, int64_t V, void* stream) {
-  NNL_CHECK_ARG(rows > 0 && V > 0 && V < (1L << 31) && rows < (1L << 31), "softmax_ce_bwd: bad sizes");
+                                  float* dlogits, int64_t rows, int64_t V, int64_t ld_dlogits, void* stream) {
+  NNL_CHECK_ARG(rows > 0 && V > 0 && V < (1L << 31) && rows < (1L << 31) && ld_dlogits >= V, "softmax_ce_bwd: bad sizes");
   NNL_CHECK_ARG(logits && target && lse && grad_out && dlogits, "softmax_ce_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
   NnlProfScope prof(NNL_PROF_SOFTMAX_CE, s, 8.0 * rows * V);
   hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3((unsigned)rows), dim3(kBlock), 0, s, logits, target, lse, grad_out, dlogits, (int)V,
-                     (long)rows);
+                     (long)rows, (long)ld_dlogits);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

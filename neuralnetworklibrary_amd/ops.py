@@ -177,6 +177,35 @@ def finish_backward():
     _WT_ACTIVE.clear()
 
 
+# Gradient buffers whose rows are ALREADY padded with zeros to the GEMM granularity (the softmax-CE backward at V % 16 != 0, the
+# LSTM's dgates at 4H % 32 != 0): the producer registers the padded base tensor, hands autograd the [:, :K] view, and the linear
+# layer that receives it (through whatever reshape / permute views autograd inserts) recognises its base and uses the padded rows
+# directly.  Keyed by id() and guarded by a weak reference, so a recycled id can never match.
+_PADDED_GRADS = {}
+
+
+def register_padded_grad(base, ld):
+    import weakref
+    if len(_PADDED_GRADS) > 64:
+        for k in [k for k, (r, _) in _PADDED_GRADS.items() if r() is None]:
+            del _PADDED_GRADS[k]
+    _PADDED_GRADS[id(base)] = (weakref.ref(base), int(ld))
+
+
+def _padded_rows(dy, K):
+    "dy logical [N, K, 1, 1]: the [N,1,1,ld] tensor over its registered zero-padded base, or None"
+    base = dy._base if dy._is_view() else None
+    ent = _PADDED_GRADS.get(id(base)) if base is not None else None
+    if ent is None or ent[0]() is not base or dy.dim() != 4 or dy.shape[2] != 1 or dy.shape[3] != 1:
+        return None
+    ld = ent[1]
+    if dy.dtype != torch.float32 or dy.stride(1) != 1 or dy.stride(0) != ld or ld < K or ld % 16 != 0 or dy.storage_offset() % ld != 0:
+        return None
+    if dy.storage_offset() + dy.shape[0] * ld > base.numel():
+        return None
+    return torch.as_strided(base, (dy.shape[0], 1, 1, ld), (ld, ld, ld, 1), dy.storage_offset())
+
+
 _TILE_COUNTERS = {}
 
 
@@ -256,6 +285,15 @@ class _Conv2d(torch.autograd.Function):
             return (None,) * 9
         xn, wn, y = ctx.saved_tensors
         g = ctx.g
+        pre = _padded_rows(dy, g.K) if (not ctx.relu and g.R == 1 and g.S == 1 and g.H == 1 and g.W == 1) else None
+        if pre is not None and pre.shape[-1] != g.K:
+            # the gradient arrived in a zero-padded buffer: run every pass on the padded K (zero channels contribute nothing)
+            dyn = pre
+            K = g.K
+            padk = dyn.shape[-1] - K
+            wn = torch.nn.functional.pad(wn, (0, 0, 0, 0, 0, 0, 0, padk))
+            g = _geom(g.N, g.H, g.W, g.C, K + padk, g.R, g.S, g.stride, g.pad)
+            return _Conv2d._backward_padded(ctx, dyn, wn, xn, g, K)
         dyn = to_nhwc(dy.float())
         db_gated = None
         if ctx.relu and os.environ.get('NNL_RELU_GATE', '1') == '0':
@@ -332,6 +370,36 @@ class _Conv2d(torch.autograd.Function):
             check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, ptr(cws), cb, stream()))
             db = db_full[:K]
         return dx, dw, db, None, None, None, None, None, None
+
+
+def _conv2d_backward_padded(ctx, dyn, wn, xn, g, K):
+    """backward of a linear layer (1x1 "image") whose output gradient dyn [N,1,1,Kp] is already zero-padded from K to Kp = g.K
+    channels: dgrad and wgrad on the padded K, bias gradient from the first K columns"""
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
+        check(lib.nnl_conv2d_weight_transpose(ptr(wn), ptr(wt), g.K, g.R, g.S, g.C, stream()))
+        dxn = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyn.device)
+        wsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g))
+        dws = torch.empty(wsb // 4, dtype=torch.float32, device=dyn.device) if wsb else None
+        check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, None, ptr(dws), wsb, ptr(_tile_counters(dyn.device) if wsb else None), stream()))
+        dx = from_nhwc(dxn[..., :ctx.c_in] if ctx.c_in != g.C else dxn)
+    if ctx.needs_input_grad[1]:
+        dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
+        ws_bytes = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
+        ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dyn.device)
+        check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
+        dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+        db_full = torch.empty(g.K, dtype=torch.float32, device=dyn.device)
+        cb = int(lib.nnl_colsum_workspace_bytes(g.N * g.P * g.Q, g.K))
+        cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device)
+        check(lib.nnl_colsum(ptr(dyn), ptr(db_full), g.N * g.P * g.Q, g.K, ptr(cws), cb, stream()))
+        db = db_full[:K]
+    return dx, dw, db, None, None, None, None, None, None
+
+
+_Conv2d._backward_padded = staticmethod(_conv2d_backward_padded)
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, grad_slot=None, give_slot=None):

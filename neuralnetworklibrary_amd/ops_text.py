@@ -75,6 +75,9 @@ class _LSTMRecurrence(torch.autograd.Function):
             wws = torch.empty(max(wb // 4, 1), dtype=torch.float32, device=dev)
             check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, Gp)), ptr(dwp), g, ptr(wws), wb, stream()))
             dw = dwp[:G, :H]
+        if Gp != G:
+            from .ops import register_padded_grad
+            register_padded_grad(dgates, Gp)                 # rows already padded with zeros: the input GEMM's backward uses them as is
         return dgates[:, :, :G], dw, dh0.view_as(h0), dc0.view_as(c0)
 
 
@@ -143,11 +146,18 @@ class _SoftmaxCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         logits, target, lse = ctx.saved_tensors
+        from .ops import register_padded_grad
         g = _f32c(dloss).view(1)
-        dlogits = torch.empty_like(logits)
-        check(lib.nnl_softmax_ce_bwd(ptr(logits), ptr(target), ptr(lse), ptr(g), ptr(dlogits), logits.shape[0], logits.shape[1],
-                                     stream()))
-        return dlogits, None
+        rows, V = logits.shape
+        Vp = (V + 15) // 16 * 16
+        # rows padded to the GEMM granularity (zeros in the pad columns): the producing linear layer's backward uses the buffer as
+        # is instead of re-padding it (V = 47 343: an 848 MB fill + copy per step)
+        buf = torch.empty(rows, Vp, dtype=torch.float32, device=logits.device)
+        check(lib.nnl_softmax_ce_bwd(ptr(logits), ptr(target), ptr(lse), ptr(g), ptr(buf), rows, V, Vp, stream()))
+        if Vp == V:
+            return buf, None
+        register_padded_grad(buf, Vp)
+        return buf[:, :V], None
 
 
 def softmax_cross_entropy(logits, target):

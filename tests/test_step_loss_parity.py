@@ -128,8 +128,9 @@ def test_resnet_classifier_steps_train_mode_bn():
     """ResNet-34 body + default head at 64x64, bs 16, BatchNorm in TRAINING mode, SGD momentum, 16 steps.  At this size the
     last stages normalise over 2x2x16 values per channel and the trajectory is chaotic: the REFERENCE ARITHMETIC ITSELF
     drifts by 1e-4 after one step and 1e-2 after six between fp32 and fp64 (DESIGN.md, G6 note), so a fixed 1e-3 bound is
-    meaningless here.  Criterion: the HIP path stays as close to the fp64 oracle as the fp32 oracle does (3x its gap, floored
-    at the 95th percentile of the gaps, + 1e-3 relative); step 0 (identical weights) must agree to 1e-4.  The well-conditioned
+    meaningless here.  Criterion: the HIP path stays as close to the fp64 oracle as fp32 does (3x the running maximum of the
+    fp32-vs-fp64 separation of two fp32 oracle runs — plain, and from weights perturbed by <= 1 ulp — floored at the 95th
+    percentile, + 1e-3 relative); step 0 (identical weights) must agree to 1e-4.  The well-conditioned
     frozen-BN step is pinned by golden G6 (tests/test_vision_gpu.py)."""
     from neuralnetworklibrary_amd.Applications import Vision as V
     N, S, steps = 16, 64, 16
@@ -139,13 +140,19 @@ def test_resnet_classifier_steps_train_mode_bn():
     group = lambda n: 2 if n.startswith('head') else (0 if int(n.split('.')[1]) < 6 else 1)
     lr3 = [2e-4, 5e-4, 1e-3]
 
-    def oracle(dtype):
+    def oracle(dtype, perturb_seed=None):
         net = RNets.ImageClassificationNet(RNets.resnet34(), 2, 512, drops=(0., 0.))
         synth.fill_module_(net, seed=3)
+        if perturb_seed is not None:                      # weights moved by <= 1 ulp: the conditioning yardstick
+            gen = torch.Generator().manual_seed(perturb_seed)
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.mul_(1.0 + 2.0 ** -23 * (torch.randint(0, 3, p.shape, generator=gen).float() - 1.0))
         net = net.to(dtype)
         data = [(x.to(dtype), y) for x, y in seq]
         return _oracle_run(net, lambda n, b: nn.CrossEntropyLoss()(n(b[0]), b[1]), data, lambda n: lr3[group(n)], 1e-4, 'sgd', momentum=0.9)
     ref32, ref64 = oracle(torch.float32), oracle(torch.float64)
+    pert32 = oracle(torch.float32, perturb_seed=1)
 
     class D:
         sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
@@ -156,7 +163,8 @@ def test_resnet_classifier_steps_train_mode_bn():
     learner.model.train()
     got = np.array([learner.train1minibatch(*_to_dev(b), lr3) for b in seq])
     assert_close(got[:1], ref64[:1], 1e-4, 0, 'step 0')
-    gap = np.abs(ref32 - ref64)
+    # the separation fp32 has ALREADY shown from fp64 up to step i (two fp32 samples: plain, and from eps-perturbed weights)
+    gap = np.maximum.accumulate(np.maximum(np.abs(ref32 - ref64), np.abs(pert32 - ref64)))
     bound = 3 * np.maximum(gap, np.quantile(gap, 0.95)) + 1e-3 * np.abs(ref64) + 1e-5
     err = np.abs(got - ref64)
     assert (err <= bound).all(), 'step %d: |hip - fp64| = %.3e, fp32-vs-fp64 gap %.3e' % (int(np.argmax(err - bound)), err.max(), gap.max())
