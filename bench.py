@@ -483,8 +483,14 @@ def run_config(name, device, world, rank, clock, steps, warmup, cpu):
         wl.learner.use_graphs(True)
         dtg = clock.timed(wl.step, warmup + 3, steps)
         wl.learner.use_graphs(False)
-        out['hipgraph_step'] = {'ms_per_step': round(dtg / steps * 1e3, 3), 'value': round(wl.units_per_step * steps / dtg, 1)}
-        ms_best = min(ms, dtg / steps * 1e3)
+        msg = dtg / steps * 1e3
+        out['eager_step'] = {'ms_per_step': round(ms, 3), 'value': out['value']}
+        out['hipgraph_step'] = {'ms_per_step': round(msg, 3), 'value': round(wl.units_per_step * steps / dtg, 1)}
+        if msg < ms:                                        # headline of this config = the product's faster mode, named
+            out.update(ms_per_step=round(msg, 3), value=out['hipgraph_step']['value'],
+                       mode='whole-step hipGraph replay (Learner.use_graphs(): forward + loss + backward + fused optimizer in one graph); '
+                            'eager_step = the default per-launch path')
+        ms_best = min(ms, msg)
     else:
         ms_best = ms
     n_prof = 3
