@@ -280,3 +280,45 @@ def test_two_process_tabular_dp_keeps_tables_in_sync_and_matches_single_process(
     for k in one[2]:
         assert_close(two[0][2][k], two[1][2][k], 0, 1e-7, 'replicas agree: ' + k)
         assert_close(two[0][2][k], one[2][k], 2e-4, 2e-5, k)
+
+
+# ---- dropout ON under data parallelism: keyed masks (Learner.use_keyed_dropout) on the PRODUCT tabular net ---------------
+def _fit_tab_dropout(rank, world, port, q):
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    if world > 1:
+        dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    batches = [([x[0].to(DEV), x[1].to(DEV)], y.to(DEV)) for x, y in _tab_batches()]
+    data = _Data(nd.ShardedBatches(batches, rank, world), 8 // world)
+    cards = [9, 6, 4]
+    torch.manual_seed(0)
+    net = StructuredDataNet('cont', 3, 2, [{i: i for i in range(c)} for c in cards], [12, 1], output_range=[0, 1],
+                            dropout_levels=(0.25, 0.2, [0.1, 0.3]))       # row dropout, continuous dropout, head dropouts: all ON
+    learner = Learner('/tmp/nnl_tabdrop_%d_%d' % (world, rank), data, net, optimizer='SGD_Mom')
+    learner.use_keyed_dropout(seed=7)
+    if world > 1:
+        learner.distribute(sync_bn=True)
+    learner.model.train()
+    losses = [learner.train1minibatch(x, y, [5e-2, 5e-2], mom_batch=0.9) for x, y in data.train_dl]
+    sd = {k: v.detach().cpu().numpy() for k, v in learner.model.state_dict().items()}
+    q.put((rank, losses, sd))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_process_tabular_dp_with_dropout_on_reproduces_single_process():
+    """with masks keyed by (seed, step, request, GLOBAL sample index) the 2-rank run with EmbeddingDrop row
+    dropout, continuous dropout and the head's nn.Dropouts all ON trains exactly like the 1-rank run on the same global
+    minibatches (the product layers on the GPU; gloo between two processes on one GPU)."""
+    one = _run(1, _fit_tab_dropout)[0]
+    two = _run(2, _fit_tab_dropout)
+    for k in one[2]:
+        assert_close(two[0][2][k], two[1][2][k], 0, 1e-7, 'replicas agree: ' + k)
+        assert_close(two[0][2][k], one[2][k], 2e-4, 2e-5, k)
+    assert_close(np.mean([two[0][1], two[1][1]], axis=0), np.array(one[1]), 1e-4, 1e-6, 'loss curve')
