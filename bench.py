@@ -622,10 +622,21 @@ def worker(args):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-        ones = torch.ones(1, device=device)
-        dist.all_reduce(ones)
-        ranks_seen = int(ones.item())
+        # RCCL prints a version banner on STDOUT when the communicator is created: keep rank 0's stdout to the ONE JSON line by
+        # pointing fd 1 at stderr until the first collective has run
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+            ones = torch.ones(1, device=device)
+            dist.all_reduce(ones)
+            ranks_seen = int(ones.item())
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     clock = Clock(dist, device)
     seed = 1234 + 1 + 1000 * rank
 
@@ -657,8 +668,8 @@ def worker(args):
     torch.cuda.empty_cache()
 
     # ---- strong scaling: GLOBAL batch args.bs (north-star: >= 6.5x at 8 GPUs) ----
-    if world > 1:
-        per = max(args.bs // world, 1)
+    if world > 1 or force_dist:                      # (force_dist: rehearse the N > 1 legs on a 1-GPU box, world size 1)
+        per = max(args.bs // max(world, 1) // (8 if force_dist and world == 1 else 1), 1)
         strong = {'global_batch': per * world, 'per_gpu_batch': per}
         for tag, sync_bn, graphs in (('local_bn', False, False), ('local_bn_hipgraph', False, True), ('sync_bn', True, False)):
             w2 = resnet34_workload(device, per, seed, world, args.sz, sync_bn=sync_bn)

@@ -164,7 +164,9 @@ class _GraphedStep:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):         # records; nothing executes until replay()
+                # data parallel: RCCL's watchdog thread polls the events of earlier collectives from ANOTHER thread; in the default
+                # "global" capture mode that invalidates the capture ("operation not permitted when stream is capturing")
+                with torch.cuda.graph(graph, capture_error_mode='thread_local' if dp else 'global'):   # records; nothing executes until replay()
                     y_pred = learner.predict1minibatch(self.x)
                     self.loss = learner.loss_func(y_pred, self.y)
                     learner._backward(self.loss)
