@@ -450,7 +450,7 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
       const long rs = nnl_cdiv(Kp, k1);
       if (rs != sp) continue;                                             // same plan as a smaller sp
       const long per_cu = nnl_cdiv(tiles * rs, 256);
-      const double starve = per_cu < 4 ? pow(4.0 / per_cu, 0.3) : 1.0;
+      const double starve = per_cu < 4 ? pow(4.0 / per_cu, NNL_ENV_INT("NNL_WGRAD_STARVE_PCT", 30) * 0.01) : 1.0;   // A/B hook: exponent x100
       const double t = (double)per_cu * k1 * us_per_px * starve + (rs > 1 ? (rs + 1.0) * Mc * Nc * 4 / 4.5e6 + 3 : 0);   // reduce: rs slab reads + one write at ~4.5 TB/s
       if (t < best_t) {
         best_t = t;
