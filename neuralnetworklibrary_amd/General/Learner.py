@@ -71,23 +71,27 @@ def _batch_size(y_batch):
     return len(y_batch) if type(y_batch) != list else len(y_batch[0])
 
 
-def _raise_if_index_error():
+def _raise_if_index_error(local=False):
     """The gather kernels (embeddings, tabular front end, softmax-CE targets) skip an out-of-range index and raise a device
     flag instead of faulting; the reference's nn.Embedding / CrossEntropyLoss would have raised.  Read the flag once per
-    epoch / evaluate / predict (one D2H copy) and raise IndexError on EVERY rank of a data-parallel job."""
+    epoch / evaluate / predict (one D2H copy) and raise on EVERY rank of a data-parallel job (MAX over the ranks of the two
+    flag words: index out of range -> IndexError, persistent-LSTM grid-barrier time-out -> NnlError; the same mapping as
+    ops.raise_if_index_error).  local=True: no collective (predict())."""
     if default_device().type != 'cuda':
         return
     from .. import ops
     d = _dist()
-    if d is None:
+    if d is None or local:
         ops.raise_if_index_error()
         return
-    flag = ops.index_error_flag(default_device())
+    flag = ops._flags(default_device())                 # [index word, LSTM time-out word]
     total = flag.clone()
     d.all_reduce(total, op=d.ReduceOp.MAX)
-    if int(total.item()) != 0:
+    v = total.tolist()
+    code = (1 if v[0] else 0) | (2 if v[1] else 0)
+    if code != 0:
         flag.zero_()
-        raise IndexError("index out of range in self")
+        ops.raise_for_flag(code)
 
 
 def _own_rows(dl, y_batch):
@@ -436,7 +440,9 @@ class Learner(object):
                     B, Cl, Sc = B[0], Cl[0], Sc[0]          # bs = 1 for 'val' / 'test' bbox loaders
                     ds = self.data.val_ds if which == 'val' else self.data.test_ds
                     out.append([list_mult(B, 1 / ds.images[j]['scale']), Cl, Sc])
-        _raise_if_index_error()
+        # LOCAL check: predict() has no collective (`if rank == 0: learner.predict('test')` after DP training must not hang);
+        # the rank-uniform all-reduce of the flag lives in fit / evaluate / find_lr, which contain collectives anyway
+        _raise_if_index_error(local=True)
         if self.target_type == 'cont':
             return ARR(torch.cat(out))
         if self.target_type in ['cat', 'single_label', 'text_classify']:
@@ -595,6 +601,11 @@ class Learner(object):
         "use_graphs(): replay (or first capture) the step for this input signature; None -> run it eagerly"
         leaves = _tensor_leaves(x_batch) + _tensor_leaves(y_batch)
         if any(t is None for t in leaves) or not self.optimizer.graph_capturable() or not self.model.training:
+            return None
+        from ..dist import drop_ctx
+        if drop_ctx.enabled:
+            # keyed masks bake (step, request index) — Python ints — into the captured kernels' arguments: a replay would
+            # apply the capture step's masks for ever.  torch's own Dropout is graph-safe (Philox offset), the keyed path is not.
             return None
         if self.grad_sync is not None:
             if getattr(self, '_dp_graph_ok', None) is None:      # collectives INSIDE the forward (SyncBN, renorm sync) are not captured

@@ -152,14 +152,14 @@ extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float*
     q.idx = x; q.idx_stride = 2; q.n = (int)n; q.scale_i = g; q.scale_i_stride = 0; q.skip_row = -1;
     q.srcrow = x; q.srcrow_stride = 2;
     // dU[u] = sum g * M[item];  dM[item] = sum g * U[u]: the "column" of a launch is selected by offsetting idx / order
-    q.order = order; q.card = n_user; q.D = (int)D; q.dst = dU; q.src = M; q.ld = D; q.srcrow_col = 1;
+    q.order = order; q.card = n_user; q.D = (int)D; q.dst = dU; q.src = M; q.ld = D; q.srcrow_col = 1; q.srcrow_card = n_item;
     if ((st = nnl_det::segsum(q, 1, s))) return st;
     nnl_det::SegSumParams r = q;
-    r.idx = x + 1; r.order = order + n; r.card = n_item; r.dst = dM; r.src = U; r.srcrow = x; r.srcrow_col = 0;
+    r.idx = x + 1; r.order = order + n; r.card = n_item; r.dst = dM; r.src = U; r.srcrow = x; r.srcrow_col = 0; r.srcrow_card = n_user;
     if ((st = nnl_det::segsum(r, 1, s))) return st;
     // biases: dst[row] = sum g
     nnl_det::SegSumParams b = q;
-    b.D = 1; b.dst = dbu; b.src = g; b.ld = 1; b.srcrow = nullptr; b.scale_i = nullptr;
+    b.D = 1; b.dst = dbu; b.src = g; b.ld = 1; b.srcrow = nullptr; b.srcrow_card = 0; b.scale_i = nullptr;
     if ((st = nnl_det::segsum(b, 1, s))) return st;
     b.idx = x + 1; b.order = order + n; b.card = n_item; b.dst = dbi;
     return nnl_det::segsum(b, 1, s);

@@ -50,6 +50,7 @@ struct SegSumParams {
   float* dst;
   const float* src; long ld;                      // source row r: src + r * ld + coff
   const int64_t* srcrow; long srcrow_stride; int srcrow_col;    // null: r = sample index; else r = srcrow[i * stride + col]
+  long srcrow_card;                               // > 0: a sample whose source row is outside [0, srcrow_card) is SKIPPED (never read)
   const float* scale_i; long scale_i_stride;      // null: 1; else scale_i[c * scale_i_stride + i]
   const float* scale_row;                         // null: 1; else scale_row[row]
   long skip_row;                                  // a row that receives no gradient (padding_idx), or -1
@@ -91,6 +92,7 @@ static __global__ __launch_bounds__(256) void segsum_kernel(SegSumParams p) {
     for (int q = s; q < len; q += SL) {
       const int i = ord[pos + q];
       const long r = p.srcrow ? p.srcrow[(long)i * p.srcrow_stride + p.srcrow_col] : i;
+      if (p.srcrow_card > 0 && (r < 0 || r >= p.srcrow_card)) continue;     // bad partner index: skip, do not multiply garbage by 0
       float sc = srow;
       if (p.scale_i) sc *= p.scale_i[(long)c * p.scale_i_stride + i];
       if (d < D) acc += p.src[r * p.ld + coff + d] * sc;

@@ -17,13 +17,31 @@ __all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', '
 _ERR_FLAGS = {}
 
 
+def _flags(device):
+    key = (device.type, device.index)
+    if key not in _ERR_FLAGS:
+        _ERR_FLAGS[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return _ERR_FLAGS[key]
+
+
 def index_error_flag(device):
     """Per-device int32 flag that gather kernels set when they meet an out-of-range index (the sample is
     skipped, nothing faults).  Checked without a per-step sync by `raise_if_index_error()`."""
-    key = (device.type, device.index)
-    if key not in _ERR_FLAGS:
-        _ERR_FLAGS[key] = torch.zeros(1, dtype=torch.int32, device=device)
-    return _ERR_FLAGS[key]
+    return _flags(device)[0:1]
+
+
+def lstm_timeout_flag(device):
+    """Its own word next to the index flag: the persistent LSTM kernels store 2 here when their grid barrier times out (a gather
+    kernel's plain store of 1 into the index word can then no longer overwrite it)."""
+    return _flags(device)[1:2]
+
+
+def raise_for_flag(code):
+    "bit 0: index out of range (torch's nn.Embedding failure); bit 1: persistent-LSTM barrier time-out"
+    if code & 2:
+        raise _lib.NnlError("the persistent LSTM kernel's grid barrier timed out (results of that step are invalid)")
+    if code & 1:
+        raise IndexError("index out of range in self")
 
 
 def raise_if_index_error():
@@ -31,12 +49,11 @@ def raise_if_index_error():
     last call saw an out-of-range index.  The Learner calls this at the end of every epoch, evaluate() and predict()
     (General/Learner.py `_raise_if_index_error`, which also makes the decision rank-uniform under data parallelism)."""
     for flag in _ERR_FLAGS.values():
-        v = int(flag.item())
-        if v != 0:
+        v = flag.tolist()
+        code = (1 if v[0] else 0) | (2 if v[1] else 0)
+        if code:
             flag.zero_()
-            if v == 2:
-                raise _lib.NnlError("the persistent LSTM kernel's grid barrier timed out (results of that step are invalid)")
-            raise IndexError("index out of range in self")
+            raise_for_flag(code)
 
 
 def _f32c(t):

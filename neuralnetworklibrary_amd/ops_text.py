@@ -31,12 +31,12 @@ class _LSTMRecurrence(torch.autograd.Function):
         dev = gx.device
         y = torch.empty(T, B, H, dtype=torch.float32, device=dev)
         cy = torch.empty(T, B, H, dtype=torch.float32, device=dev)
-        from .ops import index_error_flag
+        from .ops import lstm_timeout_flag
         gates = torch.empty(T, B, G, dtype=torch.float32, device=dev)
         wsb = int(lib.nnl_lstm_workspace_bytes(T, B, H))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
         check(lib.nnl_lstm_fwd(ptr(gx), ptr(w_pad), ptr(h0), ptr(c0), ptr(y), ptr(cy), ptr(gates), T, B, H, ptr(ws), wsb,
-                               ptr(index_error_flag(dev)), stream()))
+                               ptr(lstm_timeout_flag(dev)), stream()))
         ctx.save_for_backward(w_hh, h0, c0, y, cy, gates)
         return y, y[-1].clone(), cy[-1].clone()
 
@@ -59,9 +59,9 @@ class _LSTMRecurrence(torch.autograd.Function):
         dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         wsb = int(lib.nnl_lstm_workspace_bytes(T, B, H))
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
-        from .ops import index_error_flag
+        from .ops import lstm_timeout_flag
         check(lib.nnl_lstm_bwd(ptr(dy), ptr(dhT), ptr(dcT), ptr(gates), ptr(cy), ptr(c0), ptr(w_t), ptr(dgates), ptr(dh0),
-                               ptr(dc0), T, B, H, ptr(ws), wsb, ptr(index_error_flag(dev)), stream()))
+                               ptr(dc0), T, B, H, ptr(ws), wsb, ptr(lstm_timeout_flag(dev)), stream()))
         dw = None
         if ctx.needs_input_grad[1]:
             # dW_hh[4H,H] = sum_t dgates_t^T h_{t-1}: the wgrad kernel on a 1x1 "conv" over T*B "pixels"

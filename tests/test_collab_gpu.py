@@ -101,6 +101,40 @@ def test_empty_and_out_of_range():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('atomic', [0, 1])
+def test_backward_skips_a_sample_with_one_bad_index(atomic, monkeypatch):
+    """a sample with ONE bad index (the other valid) must be skipped by the backward, not multiplied by 0 —
+    the dU pass may not read M[bad item] and the dM pass may not read U[bad user].  The tables sit inside a NaN-filled
+    arena so that an out-of-range read that lands next to them would poison the gradient."""
+    from neuralnetworklibrary_amd import ops, _lib
+    monkeypatch.setenv('NNL_SCATTER_ATOMIC', str(atomic))
+    _lib.lib.nnl_reload_env()
+    try:
+        D = 4
+        arena = torch.full((64, D), float('nan'), device=DEV)
+        U = arena[8:13].detach()                        # 5 users; row 5 of U is arena[13] = NaN
+        M = arena[24:30].detach()                       # 6 items; row 6 of M is arena[30] = NaN
+        U.copy_(torch.randn(5, D)); M.copy_(torch.randn(6, D))
+        U.requires_grad_(True); M.requires_grad_(True)
+        bu = torch.randn(5, 1, device=DEV, requires_grad=True)
+        bi = torch.randn(6, 1, device=DEV, requires_grad=True)
+        x = torch.tensor([[0, 1], [5, 0], [2, 6], [0, 0], [-1, 3], [4, -1]], device=DEV)     # samples 1, 2, 4, 5 are bad
+        dy = torch.randn(6, device=DEV)
+        ops.embdotbias(x, U, M, bu, bi, [0., 1.]).backward(dy)
+        with pytest.raises(IndexError):
+            ops.raise_if_index_error()
+        good = torch.tensor([0, 3], device=DEV)
+        Uc, Mc, buc, bic = [t.detach().clone().requires_grad_(True) for t in (U, M, bu, bi)]
+        ops.embdotbias(x[good], Uc, Mc, buc, bic, [0., 1.]).backward(dy[good])
+        for got, want in zip((U, M, bu, bi), (Uc, Mc, buc, bic)):
+            assert torch.isfinite(got.grad).all()
+            assert torch.equal(got.grad, want.grad)
+    finally:
+        monkeypatch.delenv('NNL_SCATTER_ATOMIC')
+        _lib.lib.nnl_reload_env()
+
+
+@pytest.mark.gpu
 def test_embedding_gradients_are_bitwise_reproducible_and_in_sample_order():
     """VERDICT r1 #9 / SURVEY §7: the three dense embedding-gradient scatters (EmbeddingDotBias, the tabular front end, the
     vocabulary-row-dropout embedding) add the samples of a table row in a FIXED order (rank sort + segment sum) — bit-identical

@@ -177,3 +177,32 @@ def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
         nd._FORCE_ALLREDUCE = forced
         if created:
             dist.destroy_process_group()
+
+
+def test_keyed_dropout_keeps_the_step_eager():
+    """keyed masks bake the Python step counter into the launch arguments, so a captured graph would replay the
+    capture step's masks for ever — use_graphs() + use_keyed_dropout() must run eagerly (masks change from step to step)."""
+    from neuralnetworklibrary_amd import dist as nnl_dist
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    cards = [11, 5, 7]
+    rs = np.random.RandomState(5)
+    xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=32) for c in cards], 1).astype(np.int64)).to(DEV)
+    xcont = torch.from_numpy(rs.standard_normal((32, 4)).astype(np.float32)).to(DEV)
+    batch = ([xcat, xcont], torch.from_numpy(rs.rand(32).astype(np.float32)).to(DEV))
+    torch.manual_seed(0)
+    net = StructuredDataNet('cont', 8, 4, [{i: i for i in range(c)} for c in cards], [24, 1], output_range=[0, 1],
+                            dropout_levels=(0.3, 0.3, [0, 0.5]))
+    learner = Learner('/tmp/nnl_graph_test', Data([batch], 32, 'cont'), net, optimizer='SGD')
+    learner.init_optimizer(wd=0.0)
+    learner.use_graphs(True, warmup=1).use_keyed_dropout(seed=7)
+    try:
+        learner.model.train()
+        losses = [learner.train1minibatch(batch[0], batch[1], 0.0) for _ in range(6)]     # lr 0: only the masks change
+        assert sum(g.graph is not None for g in learner._graphs.values()) == 0
+        assert len(set(losses)) > 3, losses
+    finally:
+        nnl_dist.drop_ctx.enabled = False
