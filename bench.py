@@ -248,6 +248,30 @@ class Clock:
             dt = float(t.item())
         return dt
 
+    def timed_median(self, fn, warmup, steps):
+        """timed() plus the MEDIAN per-step time (SURVEY.md §8d protocol: median of >= 50 steps after 10 warm-ups): one event per
+        step boundary recorded on torch's current stream — the stream every launch of the step is on — read after the closing
+        synchronise, so the host never waits inside the loop.  Returns (whole-job seconds, MAX over ranks; median step ms, MAX)."""
+        if self.device.type != 'cuda':
+            return self.timed(fn, warmup, steps), None
+        for i in range(warmup):
+            fn(i)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        self.sync()
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            fn(i)
+            ev[i + 1].record()
+        self.sync()
+        dt = time.perf_counter() - t0
+        med = float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]))
+        if self.dist is not None:
+            t = torch.tensor([dt, med], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt, med = float(t[0].item()), float(t[1].item())
+        return dt, med
+
 
 def profile_kinds(wl, n):
     "n extra steps with per-launch HIP events on the launch stream -> {kind: {launches, ms, work}} (nnl_prof_*)"
@@ -326,9 +350,32 @@ def _sgd_adam_step(RM, params, state, kind, lr, wd, **kw):
     RM.optimizer_step(params, [p.grad for p in params], state, [lr] * len(params), [wd] * len(params), kind, **kw)
 
 
+def _pin_process(cpus):
+    "affinity of EVERY thread of this process (the OpenMP pool exists already) -> cpus; returns the previous masks"
+    old = {}
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            old[int(tid)] = os.sched_getaffinity(int(tid))
+            os.sched_setaffinity(int(tid), cpus)
+        except OSError:
+            pass
+    return old
+
+
+def _unpin_process(old):
+    for tid, mask in old.items():
+        try:
+            os.sched_setaffinity(tid, mask)
+        except OSError:
+            pass
+
+
 def cpu_baseline_resnet(bs, sz, steps=2):
+    """north_star: "next to the reference run on the node's own host cores (core count stated)".  Two legs, both printed: 16
+    threads (the CPU share of a 1-GPU slot) and 64 threads pinned to the first 64 allowed CPUs (one socket's worth) when the
+    process is allowed that many; `value` = the faster one.  The 64-thread leg is abandoned after its warm-up step if that
+    step is already >= 2x slower than the 16-thread step (an over-subscribed host: 256 threads once measured 116 s/step)."""
     from oracle import reference_math as RM, reference_nets as RN
-    threads = _cpu_threads()
     torch.manual_seed(0)
     net = RN.ImageClassificationNet(RN.resnet34(), 2, 512).train()
     params = list(net.parameters())
@@ -342,10 +389,31 @@ def cpu_baseline_resnet(bs, sz, steps=2):
         loss.backward()
         _sgd_adam_step(RM, params, state, 'sgd', 1e-2, 1e-4)
         loss.item()
+    threads = _cpu_threads()
     dt = _cpu_time(step, steps)
+    legs = {str(threads): round(dt * 1e3, 1)}
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    if len(allowed) >= 48 and os.environ.get('NNL_BENCH_CPU64', '1') == '1':
+        n = min(64, len(allowed))
+        old = _pin_process(set(allowed[:n]))
+        torch.set_num_threads(n)
+        try:
+            t0 = time.time()
+            step()
+            warm = time.time() - t0
+            if warm < 2.0 * dt:
+                dt64 = _cpu_time(step, steps)
+                legs[str(n)] = round(dt64 * 1e3, 1)
+                if dt64 < dt:
+                    dt, threads = dt64, n
+            else:
+                legs[str(n)] = 'abandoned: warm-up step %.1f s vs %.1f s per step at 16 threads' % (warm, dt)
+        finally:
+            _unpin_process(old)
+            torch.set_num_threads(_cpu_threads())
     return dict({'value': bs / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
                  'sample': '%d steps of the same bs=%d %dx%d ResNet-34 train step (after 1 warm-up), torch-CPU oracle' % (steps, bs, sz, sz),
-                 'ms_per_step': dt * 1e3}, **host_info())
+                 'ms_per_step': dt * 1e3, 'ms_per_step_by_threads': legs}, **host_info())
 
 
 def cpu_baseline_collab(bs, steps=200):
@@ -476,16 +544,20 @@ def run_config(name, device, world, rank, clock, steps, warmup, cpu):
                         'lm': 'IMDB AWD-LSTM language model 400/1150/3, V=47343, bptt=70, bs=64 per GPU, Adam, RegSeqCrossEntropyLoss(2,1)',
                         'retinanet': 'Pascal RetinaNet (ResNet-50 FPN + FocalLoss / smooth-L1), 512x512, bs=16 per GPU, SGD momentum'}[name],
            'unit': wl.unit, 'steps': steps, 'dtype': 'f32', 'scaling': 'weak'}
-    dt = clock.timed(wl.step, warmup, steps)
+    dt, med = clock.timed_median(wl.step, warmup, steps)
     ms = dt / steps * 1e3
-    out.update(ms_per_step=round(ms, 3), value=round(wl.units_per_step * world * steps / dt, 1), last_loss=wl.loss)
+    out.update(ms_per_step=round(ms, 3), median_ms_per_step=None if med is None else round(med, 3),
+               value=round(wl.units_per_step * world * steps / dt, 1), last_loss=wl.loss,
+               protocol='%d timed steps after %d warm-ups: value / ms_per_step = whole-job wall clock (barrier + synchronise on both sides, '
+                        'MAX over ranks); median_ms_per_step = median of the per-step device times (SURVEY 8d)' % (steps, warmup))
     if name in ('collab', 'tabular') and world == 1:        # launch-bound heads: the captured whole-step hipGraph (Learner.use_graphs)
         wl.learner.use_graphs(True)
-        dtg = clock.timed(wl.step, warmup + 3, steps)
+        dtg, medg = clock.timed_median(wl.step, warmup + 3, steps)
         wl.learner.use_graphs(False)
         msg = dtg / steps * 1e3
-        out['eager_step'] = {'ms_per_step': round(ms, 3), 'value': out['value']}
-        out['hipgraph_step'] = {'ms_per_step': round(msg, 3), 'value': round(wl.units_per_step * steps / dtg, 1)}
+        out['eager_step'] = {'ms_per_step': round(ms, 3), 'median_ms_per_step': out['median_ms_per_step'], 'value': out['value']}
+        out['hipgraph_step'] = {'ms_per_step': round(msg, 3), 'median_ms_per_step': None if medg is None else round(medg, 3),
+                                'value': round(wl.units_per_step * steps / dtg, 1)}
         if msg < ms:                                        # headline of this config = the product's faster mode, named
             out.update(ms_per_step=round(msg, 3), value=out['hipgraph_step']['value'],
                        mode='whole-step hipGraph replay (Learner.use_graphs(): forward + loss + backward + fused optimizer in one graph); '
@@ -546,6 +618,15 @@ def dp_diagnostics(wl, clock, dist, steps, ms_dp):
         for h in hs:
             h.wait()
     ar_ms = clock.timed(allreduce_only, 2, reps) / reps * 1e3
+    # each bucket alone (so that the first real N = 8 run can be read bucket by bucket: size -> ms -> bus GB/s)
+    per_bucket = []
+    world = dist.get_world_size()
+    for b in gs.buckets:
+        one = lambda _i, b=b: dist.all_reduce(b.flat, op=dist.ReduceOp.AVG)
+        ms_b = clock.timed(one, 1, 3) / 3 * 1e3
+        mb = b.numel * 4 / 2 ** 20
+        per_bucket.append({'mbytes': round(mb, 2), 'ms': round(ms_b, 3),
+                           'bus_gbs': round(2.0 * (world - 1) / max(world, 1) * b.numel * 4 / (ms_b * 1e-3) / 1e9, 1) if ms_b > 0 else None})
     learner = wl.learner
     learner.grad_sync = None
     learner.optimizer.attach_grad_sync(None)
@@ -555,7 +636,8 @@ def dp_diagnostics(wl, clock, dist, steps, ms_dp):
     exposed = max(ms_dp - ms_nosync, 0.0)
     return {'grad_buckets': len(gs.buckets), 'grad_mbytes': round(sum(b.numel for b in gs.buckets) * 4 / 2 ** 20, 1),
             'grads_written_in_place': '%d of %d tensors per step' % (gs.direct_writes // max(gs.steps, 1), sum(len(b.params) for b in gs.buckets)),
-            'allreduce_ms_per_step_standalone': round(ar_ms, 3), 'ms_per_step_without_allreduce': round(ms_nosync, 3),
+            'allreduce_ms_per_step_standalone': round(ar_ms, 3), 'allreduce_per_bucket': per_bucket,
+            'ms_per_step_without_allreduce': round(ms_nosync, 3),
             'exposed_comm_ms_per_step': round(exposed, 3),
             'overlap_frac': round(1.0 - exposed / ar_ms, 3) if ar_ms > 0 else None}
 
@@ -707,8 +789,11 @@ def worker(args):
         names = ['collab', 'tabular', 'lm', 'retinanet'] if args.configs == 'all' else args.configs.split(',')
         out['configs'] = {}
         for name in names:
-            k = {'collab': max(args.steps, 50), 'tabular': max(args.steps, 30), 'lm': min(args.steps, 10), 'retinanet': min(args.steps, 5)}[name]
-            out['configs'][name] = run_config(name, device, world, rank, clock, k, 3, cpu)
+            # >= 50 timed steps after 10 warm-ups for every side config (RetinaNet: 50 x ~57 ms = 3 s), unless the
+            # caller asks for a quick run (--steps < 10)
+            quick = args.steps < 10
+            k = {'collab': 200, 'tabular': 100, 'lm': 50, 'retinanet': 50}[name] if not quick else max(args.steps, 3)
+            out['configs'][name] = run_config(name, device, world, rank, clock, k, 10 if not quick else 3, cpu)
     if cpu:
         out['cpu_baseline'] = cpu_baseline_resnet(args.bs, args.sz)
     if rank == 0:

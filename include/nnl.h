@@ -87,7 +87,8 @@ typedef struct {
   int32_t P, Q;         /* output spatial size */
 } nnl_conv_geom_t;
 
-/* y = conv(x, w) (+ bias[K]) (then ReLU if relu!=0).  bias may be NULL.
+/* y = act(conv(x, w) (+ bias[K])); `relu` selects the output activation: 0 none, 1 ReLU, 2 sigmoid (ClassificationModel's
+ * `output_act`, reference retinanet.py:286; needs C % 16 == 0).  bias may be NULL.
  * workspace (optional, nnl_conv2d_fwd_workspace_bytes(g); NULL = none): lets the launch use the balanced schedule —
  * when the tile grid is not a multiple of the 256 CUs, the last tiles (or all of them) are cut into k slices whose
  * partial slabs are summed in a fixed order (bitwise reproducible run to run). */
@@ -106,6 +107,13 @@ int64_t nnl_conv2d_tile_counters(void);
 int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
                    int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, float* bn_partials,
                    const float* bn_pivot, int32_t* bn_rows, void* stream);
+/* y = conv(x, w) + bias + nearest-x2-upsample(small), small = [N, P/2, Q/2, K]: the FPN top-down merge `P5_upsampled + P4_1(C4)`,
+ * `P3_1(C3) + P4_upsampled` (reference retinanet.py:126-148: nn.Upsample(scale_factor=2, mode='nearest') + add) inside the
+ * lateral convolution's epilogue.  P, Q even; C % 16 == 0. */
+int nnl_conv2d_fwd_add_up2(const float* x, const float* w, const float* bias, const float* small, float* y,
+                           const nnl_conv_geom_t* g, void* stream);
+/* its gradient with respect to `small`: dsmall[n,h,w,c] = sum of the 2x2 block of dy[N,2h,2w,C] (upsample_nearest2d backward). */
+int nnl_upsample2_bwd(const float* dy, float* dsmall, int64_t N, int64_t h, int64_t w, int64_t C, void* stream);
 /* wt[C,R,S,K] = transpose of w[K,R,S,C] over (K,C): the B operand of dgrad. */
 int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream);
 /* The same transpose for MANY filters in one launch (all convolutions of a model, once per backward pass instead of one small
@@ -140,6 +148,10 @@ int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* wor
  * pass over dy and y.  Workspace (only with colsum): nnl_colsum_workspace_bytes(rows, cols). */
 int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* The same pass for either fused output activation of nnl_conv2d_fwd: act 1 = ReLU gate (as above), act 2 = sigmoid gate
+ * g = dy * y * (1 - y) with y the sigmoid's output (torch's sigmoid_backward; retinanet.py:286 under autograd). */
+int nnl_act_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols, int act,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K2: BatchNorm fused with the residual add and ReLU that follow it ---------------------------------
  * Replaces nn.BatchNorm2d + `out += residual` + ReLU of BasicBlock/Bottleneck.forward (retinanet.py:47-48,53-57,
@@ -337,6 +349,20 @@ int nnl_softmax_ce_fwd(const float* logits, const int64_t* target, float* lse, f
  * padded to the GEMM granularity saves the consumer an 848 MB pad copy at V = 47 343). */
 int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, const float* lse, const float* grad_out,
                        float* dlogits, int64_t rows, int64_t V, int64_t ld_dlogits, void* stream);
+/* AR / TAR regularisers of RegSeqCrossEntropyLoss (Text.py:765-777) on h = enc_out [T, R] (R = bs * emb_dim, contiguous):
+ * out3[0] = alpha * mean(h^2) + beta * mean((h[1:] - h[:-1])^2), out3[1] = mean(h^2), out3[2] = the second mean; fixed-order
+ * two-stage sums (bitwise reproducible).  Backward: dh = *grad_out (device scalar, NULL = 1) * d out3[0] / dh. */
+size_t nnl_seq_reg_workspace_bytes(int64_t T, int64_t R);
+int nnl_seq_reg_fwd(const float* h, float* out3, int64_t T, int64_t R, float alpha, float beta, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int nnl_seq_reg_bwd(const float* h, const float* grad_out, float* dh, int64_t T, int64_t R, float alpha, float beta, void* stream);
+/* WeightDropLSTM1's weight drop (Text.py:495-513: W = Dropout_p(W_hh_raw), one mask per forward call) fused with the zero
+ * padding / un-padding of the recurrent matrix: out[r, c] = src[r*ld_src + c] * m(r, c) for c < H and 0 for H <= c < ld_out.
+ * m = mask[r*H + c] when mask != NULL (an explicit, already scaled mask: parity tests, keyed dropout); otherwise
+ * m = [u(seed, r*H + c) >= p] / (1 - p) from a counter-based hash (p = 0: m = 1, a padded copy).  The same call with
+ * (src = dW, ld_src = its row stride, ld_out = H) is the backward: dW_raw = dW * m — no mask tensor is stored. */
+int nnl_weight_drop(const float* src, int64_t ld_src, const float* mask, float* out, int64_t ld_out, int64_t rows, int64_t H,
+                    uint64_t seed, float p, void* stream);
 
 /* ---- K8: fused multi-tensor Optimizer.step ------------------------------------------------------------------------
  * Replaces Optimizer.step (General/Optimizer.py:58-70): decoupled weight decay X *= 1 - wd_g*lr_g (:60-67), global-norm

@@ -177,8 +177,10 @@ class WeightDropLSTM1(nn.Module):
         p = self.lstm
         if weight_mask is None and self.training and self.weight_drop.p > 0:
             weight_mask = keyed_mask(p.weight_hh_l0_raw.shape, self.weight_drop.p, p.weight_hh_l0_raw.device)   # None unless keyed
-        w_hh = self.weight_drop(p.weight_hh_l0_raw) if weight_mask is None else p.weight_hh_l0_raw * weight_mask
-        return ops.lstm_layer(x, h0c0[0], h0c0[1], p.weight_ih_l0, w_hh, p.bias_ih_l0, p.bias_hh_l0)
+        # W = Dropout_p(W_raw) (Text.py:511) is applied INSIDE the layer: one pass that also pads W for the recurrence kernels
+        drop_p = self.weight_drop.p if (self.training and weight_mask is None) else 0.0
+        return ops.lstm_layer(x, h0c0[0], h0c0[1], p.weight_ih_l0, p.weight_hh_l0_raw, p.bias_ih_l0, p.bias_hh_l0,
+                              weight_mask=weight_mask, weight_p=drop_p)
 
 
 class LSTM_Encoder(nn.Module):
@@ -339,6 +341,9 @@ class RegSeqCrossEntropyLoss(object):
         preds, enc_out = outputs
         loss = ops.cross_entropy_nd(preds, target)
         self.cross_entropy = loss.detach()
+        if enc_out.is_cuda and enc_out.dim() == 3 and (self.alpha > 0 or self.beta > 0):
+            # alpha * mean(h^2) + beta * mean((h[1:] - h[:-1])^2) in one reduction kernel (ops_text.seq_activation_reg)
+            return loss + ops.seq_activation_reg(enc_out, max(self.alpha, 0.0), max(self.beta, 0.0))
         if self.alpha > 0:
             loss = loss + self.alpha * enc_out.pow(2).mean()
         if self.beta > 0:

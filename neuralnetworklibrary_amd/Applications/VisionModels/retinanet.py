@@ -141,15 +141,29 @@ class PyramidFeatures(nn.Module):
         self.P7_1 = nn.ReLU()
         self.P7_2 = HipConv2d(feature_size, feature_size, kernel_size=3, stride=2, padding=1)
 
+    @staticmethod
+    def _fusable(lateral, big, small):
+        "1x1 / stride 1 lateral conv over `big` whose output is exactly twice `small` in both directions, C % 16 == 0"
+        return (big.is_cuda and lateral.kernel_size == (1, 1) and lateral.stride == (1, 1) and big.shape[1] % 16 == 0
+                and big.shape[2] == 2 * small.shape[2] and big.shape[3] == 2 * small.shape[3])
+
     def forward(self, inputs):
         C3, C4, C5 = inputs
         P5_x = self.P5_1(C5)
-        P5_up = self.P5_upsampled(P5_x)
-        P5_x = self.P5_2(P5_x)
-        P4_x = P5_up + self.P4_1(C4)
-        P4_up = self.P4_upsampled(P4_x)
-        P4_x = self.P4_2(P4_x)
-        P3_x = self.P3_2(self.P3_1(C3) + P4_up)
+        if self._fusable(self.P4_1, C4, P5_x) and self._fusable(self.P3_1, C3, C4):
+            # `P5_upsampled + P4_1(C4)` / `P3_1(C3) + P4_upsampled` (retinanet.py:131-141): upsample + add in the lateral
+            # convolution's epilogue (the upsampled maps are never written)
+            P4_x = ops.conv_add_upsampled(C4, self.P4_1.weight, self.P4_1.bias, P5_x)
+            P5_x = self.P5_2(P5_x)
+            P3_x = self.P3_2(ops.conv_add_upsampled(C3, self.P3_1.weight, self.P3_1.bias, P4_x))
+            P4_x = self.P4_2(P4_x)
+        else:
+            P5_up = self.P5_upsampled(P5_x)
+            P5_x = self.P5_2(P5_x)
+            P4_x = P5_up + self.P4_1(C4)
+            P4_up = self.P4_upsampled(P4_x)
+            P4_x = self.P4_2(P4_x)
+            P3_x = self.P3_2(self.P3_1(C3) + P4_up)
         P6_x = self.P6(C5)
         P7_x = self.P7_2(self.P7_1(P6_x))
         return [P3_x, P4_x, P5_x, P6_x, P7_x]
@@ -170,7 +184,7 @@ class _Head(nn.Module):
             setattr(self, 'bn%d' % i, nn.BatchNorm2d(feature_size, momentum=0.01) if bn else None)
         self.output = HipConv2d(feature_size, n_out, kernel_size=3, padding=1)
 
-    def _trunk(self, x):
+    def _trunk(self, x, sigmoid=False):
         if self.bn0:
             x = self.bn0(x)
         if self.drop0:
@@ -183,7 +197,13 @@ class _Head(nn.Module):
                 out = bn(out)
             if self.drop:
                 out = self.drop(out)
-        return self.output(out)
+        o = self.output
+        if sigmoid and out.shape[1] % 16 == 0 and o.stride == (1, 1) and o.padding[0] == o.padding[1]:
+            # `output_act` (nn.Sigmoid, retinanet.py:286) in the epilogue of the output convolution; its backward gate and the bias
+            # gradient are one pass (nnl_act_gate_colsum)
+            return ops.conv2d(out, o.weight, o.bias, 1, o.padding[0], relu=2)
+        out = o(out)
+        return self.output_act(out) if sigmoid else out
 
 
 class RegressionModel(_Head):
@@ -208,7 +228,7 @@ class ClassificationModel(_Head):
         self.output_act = nn.Sigmoid()
 
     def forward(self, x):
-        out = self.output_act(self._trunk(x))
+        out = self._trunk(x, sigmoid=True)
         return out.permute(0, 2, 3, 1).reshape(out.shape[0], -1, self.num_classes)
 
 

@@ -54,6 +54,9 @@ SIGNATURES = {
     'nnl_colsum_workspace_bytes': (sz, [i64, i64]),
     'nnl_colsum': (C.c_int, [c_p, c_p, i64, i64, c_p, sz, c_p]),
     'nnl_relu_gate_colsum': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, c_p, sz, c_p]),
+    'nnl_conv2d_fwd_add_up2': (C.c_int, [c_p, c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), c_p]),
+    'nnl_upsample2_bwd': (C.c_int, [c_p, c_p, i64, i64, i64, i64, c_p]),
+    'nnl_act_gate_colsum': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, C.c_int, c_p, sz, c_p]),
     'nnl_maxpool2d_fwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_maxpool2d_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_bn_relu_maxpool_supported': (C.c_int, [i64]),
@@ -83,6 +86,10 @@ SIGNATURES = {
     'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p, sz, c_p]),
     'nnl_softmax_ce_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p, c_p]),
     'nnl_softmax_ce_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p]),
+    'nnl_seq_reg_workspace_bytes': (sz, [i64, i64]),
+    'nnl_seq_reg_fwd': (C.c_int, [c_p, c_p, i64, i64, C.c_float, C.c_float, c_p, sz, c_p]),
+    'nnl_seq_reg_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, C.c_float, C.c_float, c_p]),
+    'nnl_weight_drop': (C.c_int, [c_p, i64, c_p, c_p, i64, i64, i64, C.c_uint64, C.c_float, c_p]),
     'nnl_optim_chunk_elems': (i64, []),
     'nnl_optim_step': (C.c_int, [c_p, c_p, c_p, i64, C.c_int, c_p, C.c_int, c_p, c_p]),
     'nnl_bn_workspace_bytes': (sz, [i64, i64]),

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   for (int sl = 1; sl < nslabs; ++sl) acc += reinterpret_cast<const f32x4*>(part)[(long)sl * slab_stride4 + i];
   if (bias) acc += reinterpret_cast<const f32x4*>(bias)[i % Nc4];
   if (add) acc += reinterpret_cast<const f32x4*>(add)[i];
-  if (relu) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+  if (relu == 1) { acc[0] = fmaxf(acc[0], 0.f); acc[1] = fmaxf(acc[1], 0.f); acc[2] = fmaxf(acc[2], 0.f); acc[3] = fmaxf(acc[3], 0.f); }
+  else if (relu == 2) { acc[0] = nnl_sigmoid(acc[0]); acc[1] = nnl_sigmoid(acc[1]); acc[2] = nnl_sigmoid(acc[2]); acc[3] = nnl_sigmoid(acc[3]); }
   reinterpret_cast<f32x4*>(out)[i] = acc;
 }
 
@@ -363,9 +364,18 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 // ReLU backward gate fused with the bias-gradient column sums: g = dy * [y > 0] is written once and summed per column in the same
 // pass (the conv + bias + ReLU layers of the RetinaNet heads: two ATen kernels and one pass over dy less per layer)
-__global__ __launch_bounds__(256) void relu_gate_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                                float* __restrict__ g, float* __restrict__ part, long rows, int cols,
-                                                                long rows_per_chunk) {
+// ACT 1: ReLU gate g = dy * [y > 0];  ACT 2: sigmoid gate g = dy * y * (1 - y) (y = the sigmoid's OUTPUT: ClassificationModel,
+// retinanet.py:286 — torch's sigmoid_backward formula)
+template <int ACT>
+__device__ __forceinline__ float act_gate(float dy, float y) {
+  if (ACT == 1) return y > 0.f ? dy : 0.f;
+  return dy * ((1.f - y) * y);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void act_gate_colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               float* __restrict__ g, float* __restrict__ part, long rows, int cols,
+                                                               long rows_per_chunk) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(256) void relu_gate_colsum_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long o = (r + 4 * u) * cols + c;
-        v[u] = y[o] > 0.f ? dy[o] : 0.f;
+        v[u] = act_gate<ACT>(dy[o], y[o]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) g[(r + 4 * u) * cols + c] = v[u];
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256) void relu_gate_colsum_kernel(const float* __re
     }
     for (; r < r1; r += 4) {
       const long o = r * cols + c;
-      const float v = y[o] > 0.f ? dy[o] : 0.f;
+      const float v = act_gate<ACT>(dy[o], y[o]);
       g[o] = v;
       acc += v;
     }
@@ -628,6 +638,7 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
   int st = check_geom(g, "conv2d_fwd");
   if (st) return st;
   NNL_CHECK_ARG(x && w && y, "conv2d_fwd: null pointer");
+  NNL_CHECK_ARG(relu >= 0 && relu <= 2, "conv2d_fwd: relu (activation) must be 0 none, 1 ReLU or 2 sigmoid");
   hipStream_t s = (hipStream_t)stream;
   IgemmRowkParams p{};
   p.a = x; p.b = w; p.y = y; p.bias = bias;
@@ -654,7 +665,39 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
     q.bn_part = (bn_partials && bn_pivot && bn_rows) ? bn_partials : nullptr; q.bn_pivot = bn_pivot;
     return dispatch_taps(q, s, workspace, workspace_bytes, tile_counters, bn_rows);
   }
+  if (relu == 2) return nnl_set_error(NNL_ERR_UNSUPPORTED, "conv2d_fwd: the sigmoid epilogue needs C %% 16 == 0 (C=%d)", g->C);
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
+}
+
+/* y = conv(x, w) + bias + upsample_nearest_x2(small): the FPN top-down merge `P5_upsampled + P4_1(C4)` (reference retinanet.py:
+ * 131-141) in the lateral convolution's epilogue — the upsampled tensor is never materialised and the add is not a separate pass. */
+extern "C" int nnl_conv2d_fwd_add_up2(const float* x, const float* w, const float* bias, const float* small, float* y,
+                                      const nnl_conv_geom_t* g, void* stream) {
+  int st = check_geom(g, "conv2d_fwd_add_up2");
+  if (st) return st;
+  NNL_CHECK_ARG(x && w && y && small, "conv2d_fwd_add_up2: null pointer");
+  NNL_CHECK_ARG(g->P % 2 == 0 && g->Q % 2 == 0, "conv2d_fwd_add_up2: the output (%d x %d) must be twice the small map", g->P, g->Q);
+  const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
+  if (!taps_ok(a_elems, b_elems, g->C, g->R * g->S))
+    return nnl_set_error(NNL_ERR_UNSUPPORTED, "conv2d_fwd_add_up2: needs C %% 16 == 0 (C=%d)", g->C);
+  hipStream_t s = (hipStream_t)stream;
+  const long M = (long)g->N * g->P * g->Q;
+  NnlProfScope prof(NNL_PROF_CONV_FWD, s, 2.0 * M * (double)g->K * g->R * g->S * g->C);
+  IgemmTapsParams q{};
+  q.a = x; q.b = w; q.y = y; q.bias = bias; q.add = small; q.add_up2 = 1;
+  q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
+  q.H = g->H; q.W = g->W; q.C = g->C; q.P = g->P; q.Q = g->Q;
+  q.in_stride = g->stride; q.ih0 = -g->pad; q.iw0 = -g->pad;
+  q.OH = g->P; q.OW = g->Q; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
+  q.M = (int)M; q.Nc = g->K; q.b_row_stride = g->R * g->S * g->C; q.relu = 0;
+  q.ntaps = g->R * g->S;
+  for (int r = 0; r < g->R; ++r)
+    for (int ss = 0; ss < g->S; ++ss) {
+      const int t = r * g->S + ss;
+      q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
+      q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
+    }
+  return dispatch_taps(q, s);            // no workspace: the plain grid (the split-tile fix-up path reads a same-shape addend only)
 }
 
 extern "C" int nnl_conv2d_weight_transpose(const float* w, float* wt, int K, int R, int S, int C, void* stream) {
@@ -826,17 +869,22 @@ extern "C" size_t nnl_colsum_workspace_bytes(int64_t rows, int64_t cols) {
   return (size_t)colsum_chunks(rows) * cols * sizeof(float);
 }
 
-extern "C" int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols,
-                                    void* workspace, size_t workspace_bytes, void* stream) {
-  NNL_CHECK_ARG(dy && y && g && rows > 0 && cols > 0 && cols < (1L << 30), "relu_gate_colsum: bad argument");
+extern "C" int nnl_act_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols, int act,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(dy && y && g && rows > 0 && cols > 0 && cols < (1L << 30), "act_gate_colsum: bad argument");
+  NNL_CHECK_ARG(act == 1 || act == 2, "act_gate_colsum: act must be 1 (ReLU) or 2 (sigmoid)");
   if (colsum != nullptr && (workspace == nullptr || workspace_bytes < nnl_colsum_workspace_bytes(rows, cols)))
-    return nnl_set_error(NNL_ERR_WORKSPACE, "relu_gate_colsum: workspace too small");
+    return nnl_set_error(NNL_ERR_WORKSPACE, "act_gate_colsum: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 12.0 * rows * cols);
   const int nchunk = colsum_chunks(rows);
   const long rpc = nnl_cdiv(nnl_cdiv(rows, nchunk), 4) * 4;
-  hipLaunchKernelGGL(relu_gate_colsum_kernel, dim3((unsigned)nnl_cdiv(cols, 64), nchunk), dim3(256), 0, s, dy, y, g,
-                     colsum ? (float*)workspace : nullptr, (long)rows, (int)cols, rpc);
+  const dim3 grid((unsigned)nnl_cdiv(cols, 64), nchunk);
+  float* part = colsum ? (float*)workspace : nullptr;
+  if (act == 1)
+    hipLaunchKernelGGL(act_gate_colsum_kernel<1>, grid, dim3(256), 0, s, dy, y, g, part, (long)rows, (int)cols, rpc);
+  else
+    hipLaunchKernelGGL(act_gate_colsum_kernel<2>, grid, dim3(256), 0, s, dy, y, g, part, (long)rows, (int)cols, rpc);
   NNL_CHECK_LAUNCH();
   if (colsum != nullptr) {
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)nnl_cdiv(cols, 16)), dim3(256), 0, s, (const float*)workspace, colsum,
@@ -844,6 +892,11 @@ extern "C" int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, f
     NNL_CHECK_LAUNCH();
   }
   return NNL_OK;
+}
+
+extern "C" int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  return nnl_act_gate_colsum(dy, y, g, colsum, rows, cols, 1, workspace, workspace_bytes, stream);
 }
 
 extern "C" int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,

@@ -52,7 +52,8 @@ struct IgemmTapsParams {
   int M, Nc;
   int b_row_stride;
   int ntaps;
-  int relu, grid_m, grid_n;
+  int add_up2;                         // 1: `add` is [N][OH/2][OW/2][Nc] and is read through a nearest-neighbour x2 upsampling (FPN top-down path)
+  int relu, grid_m, grid_n;            // relu: output activation of the final values — 0 none, 1 ReLU, 2 sigmoid
   int ksplit;                          // >1: blockIdx.y picks a contiguous range of k tiles, result goes to slab y + blockIdx.y*slab_stride
   long slab_stride;                    //     (no bias / add / ReLU in that mode; the consumer sums the slabs in a fixed order)
   // Balanced schedule (bal != 0; dense outputs only; grid.x = n_main_tiles*main_ks + n_tail_tiles*tail_slices): on 256 CUs a
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       const long o = (long)row * p.Nc + c4;
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
       if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
-      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      else if (p.relu == 2) { v[0] = nnl_sigmoid(v[0]); v[1] = nnl_sigmoid(v[1]); v[2] = nnl_sigmoid(v[2]); v[3] = nnl_sigmoid(v[3]); }
       *reinterpret_cast<f32x4*>(p.y + o) = v;
       if (p.bn_part) {
         const f32x4 pv = *reinterpret_cast<const f32x4*>(p.bn_pivot + c4);
@@ -596,18 +598,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + row_h;
         if (cok && row < p.M) {
-          long pix = row;
-          if (!dense_out) {
+          long pix = row, apix = row;
+          if (!dense_out || p.add_up2) {
             const int n = row / PQ;
             const int rem = row - n * PQ;
             const int pp = rem / p.Q;
             const int qq = rem - pp * p.Q;
-            pix = ((long)n * p.OH + pp * p.out_stride + oh0) * p.OW + qq * p.out_stride + ow0;
+            const int oh = pp * p.out_stride + oh0, ow = qq * p.out_stride + ow0;
+            pix = ((long)n * p.OH + oh) * p.OW + ow;
+            apix = p.add_up2 ? ((long)n * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1) : pix;
           }
           float v = acc[i][j][e] + bv;
           if (!partial) {
-            if (p.add) v += p.add[pix * p.Nc + col];
-            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.add) v += p.add[apix * p.Nc + col];
+            if (p.relu == 1) v = fmaxf(v, 0.f);
+            else if (p.relu == 2) v = nnl_sigmoid(v);                 // ClassificationModel's output activation (retinanet.py:286)
           }
           yout[(pix - row0) * p.Nc + col] = v;
         }
@@ -626,7 +631,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + row_h;
       if (row < p.M) {
         float v = acc[0][0][e] + bv;
-        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.relu == 1) v = fmaxf(v, 0.f);
+        else if (p.relu == 2) v = nnl_sigmoid(v);
         const float d = v - piv;
         s1 += d; s2 += d * d;
       }

@@ -188,3 +188,35 @@ extern "C" int nnl_concat_pool_bwd(const float* dout, const int32_t* argmax, flo
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
+
+
+// ---- gradient of a nearest-neighbour x2 upsampling (FPN top-down path, reference retinanet.py:131-141: nn.Upsample(scale_factor=2)) ----
+// dsmall[n][h][w][c] = dy[n][2h][2w][c] + dy[n][2h][2w+1][c] + dy[n][2h+1][2w][c] + dy[n][2h+1][2w+1][c]   (torch's order)
+// HBM-bound: 4 B read per dy element + 1 B written; 16-B accesses, one float4 of channels per thread.
+namespace {
+__global__ __launch_bounds__(256) void upsample2_bwd_kernel(const float* __restrict__ dy, float* __restrict__ ds, long total4, int h, int w, int C4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int x = (int)(r % w); r /= w;
+    const int y = (int)(r % h);
+    const long n = r / h;
+    const f32x4* src = reinterpret_cast<const f32x4*>(dy) + ((n * 2 * h + 2 * y) * 2 * w + 2 * x) * C4 + c;
+    const f32x4 a = src[0], b = src[C4], cc = src[(long)2 * w * C4], d = src[(long)2 * w * C4 + C4];
+    reinterpret_cast<f32x4*>(ds)[i] = ((a + b) + cc) + d;
+  }
+}
+}  // namespace
+
+extern "C" int nnl_upsample2_bwd(const float* dy, float* dsmall, int64_t N, int64_t h, int64_t w, int64_t C, void* stream) {
+  NNL_CHECK_ARG(dy && dsmall && N > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, "upsample2_bwd: bad argument (C %% 4 == 0)");
+  NNL_CHECK_ARG(N * h * w * C * 4 < (1L << 40), "upsample2_bwd: tensor too large");
+  hipStream_t s = (hipStream_t)stream;
+  const long total4 = N * h * w * (C / 4);
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 20.0 * N * h * w * C);
+  long blocks = nnl_cdiv(total4, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dy, dsmall, total4, (int)h, (int)w, (int)(C / 4));
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}

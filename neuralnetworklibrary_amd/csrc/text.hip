@@ -200,3 +200,152 @@ extern "C" int nnl_softmax_ce_bwd(const float* logits, const int64_t* target, co
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
+
+// ---- AR / TAR regularisers of RegSeqCrossEntropyLoss (reference Text.py:765-777) ---------------------------------------------
+//   reg = alpha * mean(h^2) + beta * mean((h[1:] - h[:-1])^2),   h = enc_out [T, R] (R = bs * emb_dim), contiguous.
+// HBM-bound: forward reads h once (4 B/element: a block owns a strip of columns and walks t, so h[t-1] stays in a register),
+// backward reads h and writes dh (8 B/element; the t-1 / t+1 neighbours are L2 hits).  Two fixed-order stages: reproducible.
+namespace {
+
+constexpr int kRegBlock = 256;
+constexpr int kRegMaxBlocks = 1024;
+
+__global__ __launch_bounds__(kRegBlock) void seq_reg_partial_kernel(const float* __restrict__ h, float* __restrict__ part, int T, long R) {
+  __shared__ float red[2][kRegBlock];
+  float ar = 0.f, tar = 0.f;
+  for (long c = (long)blockIdx.x * kRegBlock + threadIdx.x; c < R; c += (long)gridDim.x * kRegBlock) {
+    float prev = h[c];
+    ar += prev * prev;
+    for (int t = 1; t < T; ++t) {
+      const float v = h[(long)t * R + c];
+      const float d = v - prev;
+      ar += v * v;
+      tar += d * d;
+      prev = v;
+    }
+  }
+  red[0][threadIdx.x] = ar; red[1][threadIdx.x] = tar;
+  __syncthreads();
+  for (int w = kRegBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { part[2 * blockIdx.x] = red[0][0]; part[2 * blockIdx.x + 1] = red[1][0]; }
+}
+
+// out[0] = alpha*ar + beta*tar, out[1] = ar = mean(h^2), out[2] = tar
+__global__ __launch_bounds__(kRegBlock) void seq_reg_final_kernel(const float* __restrict__ part, int nparts, float* __restrict__ out,
+                                                                    float alpha, float beta, float inv_n_ar, float inv_n_tar) {
+  __shared__ float red[2][kRegBlock];
+  float ar = 0.f, tar = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += kRegBlock) { ar += part[2 * i]; tar += part[2 * i + 1]; }
+  red[0][threadIdx.x] = ar; red[1][threadIdx.x] = tar;
+  __syncthreads();
+  for (int w = kRegBlock / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) { red[0][threadIdx.x] += red[0][threadIdx.x + w]; red[1][threadIdx.x] += red[1][threadIdx.x + w]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float a = red[0][0] * inv_n_ar, t = red[1][0] * inv_n_tar;
+    out[1] = a; out[2] = t;
+    out[0] = alpha * a + beta * t;
+  }
+}
+
+// dh[t] = g * ( ca * h[t] + cb * ((t > 0 ? h[t] - h[t-1] : 0) - (t < T-1 ? h[t+1] - h[t] : 0)) ),  ca = 2 alpha / N_ar, cb = 2 beta / N_tar
+__global__ __launch_bounds__(kRegBlock) void seq_reg_bwd_kernel(const float* __restrict__ h, const float* __restrict__ gout,
+                                                                  float* __restrict__ dh, int T, long R, float ca, float cb) {
+  const float g = gout ? gout[0] : 1.f;
+  const long total = (long)T * R;
+  for (long i = (long)blockIdx.x * kRegBlock + threadIdx.x; i < total; i += (long)gridDim.x * kRegBlock) {
+    const int t = (int)(i / R);
+    const float v = h[i];
+    float d = 0.f;
+    if (t > 0) d += v - h[i - R];
+    if (t < T - 1) d -= h[i + R] - v;
+    dh[i] = g * (ca * v + cb * d);
+  }
+}
+
+// ---- WeightDropLSTM1's weight drop (reference Text.py:495-513: `W = Dropout_p(W_raw)`, resampled once per forward, shared by all
+// timesteps), fused with the zero-padding of the recurrent matrix to the persistent kernel's k granularity:
+//   out[r][c] = raw[r][c] * m(r, c) for c < H, 0 for H <= c < ld_out;   m = mask[r*H + c] when a mask is given, else
+//   keep(seed, r*H + c) / (1 - p) with keep = [u >= p], u = 24 uniform bits of a splitmix64 hash of (seed, index).
+// The backward re-derives m the same way (no mask tensor is stored): draw[r][c] = dW[r*ld_dw + c] * m(r, c).
+__device__ __forceinline__ float wd_keep(unsigned long long seed, unsigned long long idx, float p, float scale) {
+  unsigned long long x = seed + idx * 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x = x ^ (x >> 31);
+  const float u = (float)(unsigned)(x >> 40) * (1.0f / 16777216.0f);
+  return u >= p ? scale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void weight_drop_kernel(const float* __restrict__ src, long ld_src, const float* __restrict__ mask,
+                                                           float* __restrict__ out, long ld_out, long rows, int H,
+                                                           unsigned long long seed, float p, float scale, int use_hash) {
+  const long total = rows * ld_out;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ld_out;
+    const int c = (int)(i - r * ld_out);
+    float v = 0.f;
+    if (c < H) {
+      const long e = r * H + c;
+      const float m = mask ? mask[e] : (use_hash ? wd_keep(seed, (unsigned long long)e, p, scale) : 1.f);
+      v = src[r * ld_src + c] * m;
+    }
+    out[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t nnl_seq_reg_workspace_bytes(int64_t T, int64_t R) {
+  return (T > 0 && R > 0) ? (size_t)kRegMaxBlocks * 2 * sizeof(float) : 0;
+}
+
+extern "C" int nnl_seq_reg_fwd(const float* h, float* out3, int64_t T, int64_t R, float alpha, float beta, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  NNL_CHECK_ARG(h && out3 && T > 0 && R > 0 && T < (1 << 30), "seq_reg_fwd: bad argument");
+  if (workspace == nullptr || workspace_bytes < nnl_seq_reg_workspace_bytes(T, R))
+    return nnl_set_error(NNL_ERR_WORKSPACE, "seq_reg_fwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 4.0 * T * R);
+  long blocks = nnl_cdiv(R, kRegBlock);
+  if (blocks > kRegMaxBlocks) blocks = kRegMaxBlocks;
+  hipLaunchKernelGGL(seq_reg_partial_kernel, dim3((unsigned)blocks), dim3(kRegBlock), 0, s, h, (float*)workspace, (int)T, (long)R);
+  NNL_CHECK_LAUNCH();
+  const float inv_ar = 1.f / ((float)T * (float)R), inv_tar = T > 1 ? 1.f / ((float)(T - 1) * (float)R) : 0.f;
+  hipLaunchKernelGGL(seq_reg_final_kernel, dim3(1), dim3(kRegBlock), 0, s, (const float*)workspace, (int)blocks, out3, alpha, beta, inv_ar, inv_tar);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_seq_reg_bwd(const float* h, const float* grad_out, float* dh, int64_t T, int64_t R, float alpha, float beta,
+                               void* stream) {
+  NNL_CHECK_ARG(h && dh && T > 0 && R > 0 && T < (1 << 30), "seq_reg_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 8.0 * T * R);
+  const float ca = 2.f * alpha / ((float)T * (float)R), cb = T > 1 ? 2.f * beta / ((float)(T - 1) * (float)R) : 0.f;
+  long blocks = nnl_cdiv(T * R, kRegBlock * 4);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(seq_reg_bwd_kernel, dim3((unsigned)blocks), dim3(kRegBlock), 0, s, h, grad_out, dh, (int)T, (long)R, ca, cb);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_weight_drop(const float* src, int64_t ld_src, const float* mask, float* out, int64_t ld_out, int64_t rows,
+                               int64_t H, uint64_t seed, float p, void* stream) {
+  NNL_CHECK_ARG(src && out && rows > 0 && H > 0 && ld_src >= H && ld_out >= H && H < (1L << 30), "weight_drop: bad argument");
+  NNL_CHECK_ARG(p >= 0.f && p < 1.f, "weight_drop: p must be in [0, 1)");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 8.0 * rows * H);
+  long blocks = nnl_cdiv(rows * ld_out, 256 * 4);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(weight_drop_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, (long)ld_src, mask, out, (long)ld_out, (long)rows,
+                     (int)H, (unsigned long long)seed, p, 1.f / (1.f - p), (mask == nullptr && p > 0.f) ? 1 : 0);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}

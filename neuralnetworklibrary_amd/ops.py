@@ -293,7 +293,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)              # no zero-filled gradient tensor for `part` in backward
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
         ctx.c_in = x.shape[1]
-        ctx.save_for_backward(xn, wn, y if relu else None)
+        ctx.save_for_backward(xn, wn, y if relu else None)        # relu: 0 none, 1 ReLU, 2 sigmoid (both gates need the OUTPUT y)
         return from_nhwc(y), part
 
     @staticmethod
@@ -313,17 +313,17 @@ class _Conv2d(torch.autograd.Function):
             return _Conv2d._backward_padded(ctx, dyn, wn, xn, g, K)
         dyn = to_nhwc(dy.float())
         db_gated = None
-        if ctx.relu and os.environ.get('NNL_RELU_GATE', '1') == '0':
+        if ctx.relu == 1 and os.environ.get('NNL_RELU_GATE', '1') == '0':
             dyn = dyn * (y > 0)
         elif ctx.relu:
-            # ReLU gate (+ the bias gradient of the gated dy) in one pass
+            # ReLU / sigmoid gate (+ the bias gradient of the gated dy) in one pass
             want_db = ctx.has_bias and ctx.needs_input_grad[2]
             rows = g.N * g.P * g.Q
             gated = torch.empty_like(dyn)
             cb = int(lib.nnl_colsum_workspace_bytes(rows, g.K)) if want_db else 0
             cws = torch.empty(max(cb // 4, 1), dtype=torch.float32, device=dyn.device) if want_db else None
             db_gated = torch.empty(g.K, dtype=torch.float32, device=dyn.device) if want_db else None
-            check(lib.nnl_relu_gate_colsum(ptr(dyn), ptr(y), ptr(gated), ptr(db_gated), rows, g.K, ptr(cws), cb, stream()))
+            check(lib.nnl_act_gate_colsum(ptr(dyn), ptr(y), ptr(gated), ptr(db_gated), rows, g.K, int(ctx.relu), ptr(cws), cb, stream()))
             dyn = gated
         K = g.K
         if K % 4 != 0:                      # e.g. RetinaNet 36/180-channel output convs: pad dy's channels
@@ -419,10 +419,81 @@ def _conv2d_backward_padded(ctx, dyn, wn, xn, g, K):
 _Conv2d._backward_padded = staticmethod(_conv2d_backward_padded)
 
 
+class _NeedsView:
+    "a Function ctx seen through another needs_input_grad (so that _Conv2d.backward can serve Functions with other input lists)"
+
+    def __init__(self, ctx, needs):
+        object.__setattr__(self, '_ctx', ctx)
+        object.__setattr__(self, 'needs_input_grad', tuple(needs) + (False,) * 6)
+
+    def __getattr__(self, name):
+        return getattr(self._ctx, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._ctx, name, value)
+
+
+def _conv_backward_core(ctx, dy, needs):
+    "(dx, dw, db) of a convolution whose ctx carries the fields _Conv2d.forward sets"
+    out = _Conv2d.backward(_NeedsView(ctx, needs), dy)
+    return out[0], out[1], out[2]
+
+
 def conv2d(x, weight, bias=None, stride=1, pad=0, relu=False, grad_slot=None, give_slot=None):
-    """y = conv2d(x, weight, bias, stride, padding=pad) [+ ReLU]; x logical [N,C,H,W], weight [K,C,R,S].
+    """y = act(conv2d(x, weight, bias, stride, padding=pad)); relu: False / 0 none, True / 1 ReLU, 2 sigmoid (fused into the
+    kernel epilogue; the backward gate and the bias gradient are one pass); x logical [N,C,H,W], weight [K,C,R,S].
     grad_slot: see GradSlot (the shortcut gradient of a residual block, added to dx inside the dgrad kernel)."""
-    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), bool(relu), grad_slot, None, give_slot)[0]
+    return _Conv2d.apply(x, weight, bias, int(stride), int(pad), int(relu), grad_slot, None, give_slot)[0]
+
+
+class _ConvAddUp2(torch.autograd.Function):
+    """conv2d(x, weight, bias) + nearest-x2-upsample(small) in ONE kernel (reference PyramidFeatures.forward,
+    retinanet.py:126-148: `P5_upsampled + P4_1(C4)`, `P3_1(C3) + P4_upsampled`); backward = the convolution's backward on dy plus
+    the 2x2 block sums of dy for `small` (nnl_upsample2_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, small, stride, pad):
+        require_cuda(x, weight, bias, small)
+        ctx.slot = ctx.give_slot = None
+        ctx.grad_dst = getattr(weight, '_nnl_grad_dst', None)
+        ctx.uses = getattr(weight, '_nnl_uses', None)
+        if ctx.uses is not None:
+            ctx.uses[0] += 1
+        xn = _pad_c4(to_nhwc(x.float()))
+        wn = _pad_c4(to_nhwc(weight.float()))
+        sn = to_nhwc(small.float())
+        N, H, W, C = xn.shape
+        K, R, S, _ = wn.shape
+        g = _geom(N, H, W, C, K, R, S, stride, pad)
+        if tuple(sn.shape) != (N, g.P // 2, g.Q // 2, K) or g.P % 2 or g.Q % 2:
+            raise _lib.NnlError('conv_add_upsampled: `small` %s is not [N, K, P/2, Q/2] of the %dx%d output' % (tuple(small.shape), g.P, g.Q))
+        y = torch.empty((N, g.P, g.Q, K), dtype=torch.float32, device=x.device)
+        b = None if bias is None else _f32c(bias)
+        check(lib.nnl_conv2d_fwd_add_up2(ptr(xn), ptr(wn), ptr(b), ptr(sn), ptr(y), g, stream()))
+        ctx.g, ctx.relu, ctx.has_bias = g, 0, bias is not None
+        ctx.c_in = x.shape[1]
+        ctx.small_shape = (N, g.P // 2, g.Q // 2, K)
+        ctx.save_for_backward(xn, wn, None)
+        return from_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dsmall = None
+        if ctx.needs_input_grad[3]:
+            dyn = to_nhwc(dy.float())
+            N, h, w, K = ctx.small_shape
+            ds = torch.empty(ctx.small_shape, dtype=torch.float32, device=dy.device)
+            check(lib.nnl_upsample2_bwd(ptr(dyn), ptr(ds), N, h, w, K, stream()))
+            dsmall = from_nhwc(ds)
+        need = ctx.needs_input_grad
+        ctx_needs = (need[0], need[1], need[2])
+        dx, dw, db = _conv_backward_core(ctx, dy, ctx_needs)
+        return dx, dw, db, dsmall, None, None
+
+
+def conv_add_upsampled(x, weight, bias, small, stride=1, pad=0):
+    "conv2d(x, weight, bias) + F.interpolate(small, scale_factor=2, mode='nearest'), fused (FPN top-down merge)"
+    return _ConvAddUp2.apply(x, weight, bias, small, int(stride), int(pad))
 
 
 def conv2d_with_bn_stats(x, weight, bias, stride, pad, bn_pivot, grad_slot=None, give_slot=None):
@@ -437,7 +508,7 @@ def linear(x, weight, bias=None, relu=False):
     are flattened into rows."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, bool(relu), None, None)[0]
+    y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, int(relu), None, None)[0]
     return y.reshape(*lead, weight.shape[0])
 
 
@@ -917,5 +988,5 @@ def retina_loss(anchors, reg, clas, boxes, cats, beta=0.5, alpha=0.25, gamma=2.0
     return _RetinaLoss.apply(anchors, reg, clas, boxes, cats, beta, alpha, gamma)
 
 
-from .ops_text import (lstm_layer, embedding_rowmask, softmax_cross_entropy, cross_entropy_nd)  # noqa: E402,F401
-__all__ += ['lstm_layer', 'embedding_rowmask', 'softmax_cross_entropy', 'cross_entropy_nd']
+from .ops_text import (lstm_layer, embedding_rowmask, softmax_cross_entropy, cross_entropy_nd, seq_activation_reg)  # noqa: E402,F401
+__all__ += ['lstm_layer', 'embedding_rowmask', 'softmax_cross_entropy', 'cross_entropy_nd', 'seq_activation_reg', 'conv_add_upsampled']

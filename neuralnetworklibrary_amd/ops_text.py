@@ -20,15 +20,25 @@ class _LSTMRecurrence(torch.autograd.Function):
     projections gx [T,B,4H]: forward = nnl_lstm_fwd, backward = nnl_lstm_bwd (BPTT) + one GEMM for dW_hh."""
 
     @staticmethod
-    def forward(ctx, gx, w_hh, h0, c0):
-        require_cuda(gx, w_hh, h0, c0)
-        gx, w_hh = _f32c(gx), _f32c(w_hh)
+    def forward(ctx, gx, w_raw, h0, c0, wmask=None, p=0.0, seed=0):
+        """w_raw [4H,H]: the RAW recurrent matrix; the weight drop W = w_raw * m (Text.py:495-513) — m = `wmask` (explicit, already
+        scaled) or Bernoulli(1-p)/(1-p) from (seed, element index) — and the zero padding to the kernels' k granularity are ONE
+        pass (nnl_weight_drop); the backward re-derives m for dW_raw = dW * m."""
+        require_cuda(gx, w_raw, h0, c0, wmask)
+        gx, w_raw = _f32c(gx), _f32c(w_raw)
         T, B, G = gx.shape
         H = G // 4
         h0, c0 = _f32c(h0).view(B, H), _f32c(c0).view(B, H)
         Hp = int(lib.nnl_lstm_padded_hidden(H))
-        w_pad = w_hh if Hp == H else F.pad(w_hh, (0, Hp - H))
         dev = gx.device
+        wm = None if wmask is None else _f32c(wmask)
+        ctx.drop = (wm is not None or p > 0.0, float(p), int(seed))
+        if Hp == H and not ctx.drop[0]:
+            w_pad = w_raw
+        else:
+            w_pad = torch.empty(G, Hp, dtype=torch.float32, device=dev)
+            check(lib.nnl_weight_drop(ptr(w_raw), H, ptr(wm), ptr(w_pad), Hp, G, H, int(seed), float(p), stream()))
+        w_hh = w_pad                                        # [4H, Hp]: columns >= H are zero
         y = torch.empty(T, B, H, dtype=torch.float32, device=dev)
         cy = torch.empty(T, B, H, dtype=torch.float32, device=dev)
         from .ops import lstm_timeout_flag
@@ -37,21 +47,22 @@ class _LSTMRecurrence(torch.autograd.Function):
         ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
         check(lib.nnl_lstm_fwd(ptr(gx), ptr(w_pad), ptr(h0), ptr(c0), ptr(y), ptr(cy), ptr(gates), T, B, H, ptr(ws), wsb,
                                ptr(lstm_timeout_flag(dev)), stream()))
-        ctx.save_for_backward(w_hh, h0, c0, y, cy, gates)
+        ctx.save_for_backward(w_hh, h0, c0, y, cy, gates, wm)
         return y, y[-1].clone(), cy[-1].clone()
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT):
-        w_hh, h0, c0, y, cy, gates = ctx.saved_tensors
+        w_hh, h0, c0, y, cy, gates, wm = ctx.saved_tensors
         T, B, H = y.shape
         G = 4 * H
         dev = y.device
+        Hw = w_hh.shape[1]                                  # H, or the padded row length of the dropped matrix
         dy = None if dy is None else _f32c(dy)
         dhT = None if dhT is None else _f32c(dhT)
         dcT = None if dcT is None else _f32c(dcT)
         Gp = int(lib.nnl_lstm_padded_gates(H))
-        w_t = torch.empty(H, G, dtype=torch.float32, device=dev)
-        check(lib.nnl_conv2d_weight_transpose(ptr(w_hh), ptr(w_t), G, 1, 1, H, stream()))
+        w_t = torch.empty(Hw, G, dtype=torch.float32, device=dev)        # rows >= H (the zero pad columns of w_hh) are never read
+        check(lib.nnl_conv2d_weight_transpose(ptr(w_hh), ptr(w_t), G, 1, 1, Hw, stream()))
         if Gp != G:
             w_t = F.pad(w_t, (0, Gp - G))
         dgates = torch.zeros(T, B, Gp, dtype=torch.float32, device=dev)        # pad columns must be zero
@@ -74,21 +85,29 @@ class _LSTMRecurrence(torch.autograd.Function):
             wb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
             wws = torch.empty(max(wb // 4, 1), dtype=torch.float32, device=dev)
             check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, Gp)), ptr(dwp), g, ptr(wws), wb, stream()))
-            dw = dwp[:G, :H]
+            use, p, seed = ctx.drop
+            if use:                                          # dW_raw = dW * m, un-padded in the same pass
+                dw = torch.empty(G, H, dtype=torch.float32, device=dev)
+                check(lib.nnl_weight_drop(ptr(dwp), Hp, ptr(wm), ptr(dw), H, G, H, seed, p, stream()))
+            else:
+                dw = dwp[:G, :H]
         if Gp != G:
             from .ops import register_padded_grad
             register_padded_grad(dgates, Gp)                 # rows already padded with zeros: the input GEMM's backward uses them as is
-        return dgates[:, :, :G], dw, dh0.view_as(h0), dc0.view_as(c0)
+        return dgates[:, :, :G], dw, dh0.view_as(h0), dc0.view_as(c0), None, None, None
 
 
-def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh):
-    """One-layer LSTM over x [T,B,I] with initial state (h0, c0) [1,B,H] (or [B,H]) and the given (already
-    weight-dropped) recurrent matrix.  Returns y [T,B,H], (hT [1,B,H], cT [1,B,H]) like nn.LSTM."""
+def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, weight_mask=None, weight_p=0.0):
+    """One-layer LSTM over x [T,B,I] with initial state (h0, c0) [1,B,H] (or [B,H]).  w_hh is the RAW recurrent matrix: the
+    weight drop of WeightDropLSTM1 (Text.py:495-513) happens inside (`weight_mask`: an explicit scaled mask; else a fresh
+    Bernoulli(1 - weight_p) mask per call, its seed drawn from torch's CPU generator so `torch.manual_seed` governs it).
+    Returns y [T,B,H], (hT [1,B,H], cT [1,B,H]) like nn.LSTM."""
     from . import ops
     T, B, _ = x.shape
     H = w_hh.shape[1]
     gx = ops.linear(x.reshape(T * B, -1), w_ih, b_ih + b_hh).view(T, B, 4 * H)
-    y, hT, cT = _LSTMRecurrence.apply(gx, w_hh, h0.reshape(B, H), c0.reshape(B, H))
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (weight_mask is None and weight_p > 0) else 0
+    y, hT, cT = _LSTMRecurrence.apply(gx, w_hh, h0.reshape(B, H), c0.reshape(B, H), weight_mask, float(weight_p), seed)
     return y, (hT.view(1, B, H), cT.view(1, B, H))
 
 
@@ -176,3 +195,37 @@ def cross_entropy_nd(preds, target):
         return softmax_cross_entropy(preds.permute(2, 0, 1).reshape(-1, C), target.transpose(0, 1).reshape(-1))
     perm = [0] + list(range(2, preds.dim())) + [1]
     return softmax_cross_entropy(preds.permute(*perm).reshape(-1, C), target.reshape(-1))
+
+
+class _SeqReg(torch.autograd.Function):
+    """alpha * mean(h^2) + beta * mean((h[1:] - h[:-1])^2) for h = enc_out [T, bs, E] (reference Text.py:765-777: the AR / TAR
+    terms of RegSeqCrossEntropyLoss) — one reduction pass forward, one elementwise pass backward."""
+
+    @staticmethod
+    def forward(ctx, h, alpha, beta):
+        require_cuda(h)
+        h = _f32c(h)
+        T = h.shape[0]
+        R = h.numel() // max(T, 1)
+        out = torch.empty(3, dtype=torch.float32, device=h.device)
+        wsb = int(lib.nnl_seq_reg_workspace_bytes(T, R))
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=h.device)
+        check(lib.nnl_seq_reg_fwd(ptr(h), ptr(out), T, R, float(alpha), float(beta), ptr(ws), wsb, stream()))
+        ctx.save_for_backward(h)
+        ctx.ab = (float(alpha), float(beta))
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, = ctx.saved_tensors
+        T = h.shape[0]
+        R = h.numel() // max(T, 1)
+        g = _f32c(dout).reshape(1)
+        dh = torch.empty_like(h)
+        check(lib.nnl_seq_reg_bwd(ptr(h), ptr(g), ptr(dh), T, R, ctx.ab[0], ctx.ab[1], stream()))
+        return dh, None, None
+
+
+def seq_activation_reg(enc_out, alpha, beta):
+    "AR + TAR regulariser of RegSeqCrossEntropyLoss as a 0-dim tensor (see _SeqReg)"
+    return _SeqReg.apply(enc_out, float(alpha), float(beta))

@@ -1,6 +1,8 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.  Deterministic synthetic parameters / inputs shared by the golden generator
 (reference side) and the tests (oracle + product side), so that big models need no multi-MB weight fixtures:
 both sides fill the SAME closed-form values into identically named tensors."""
+import zlib
+
 import numpy as np
 import torch
 
@@ -48,3 +50,84 @@ def fill_detection_net_(net, seed=0):
             elif name == 'classifier.output.bias':
                 p.sub_(2.0)
     return net
+
+
+def fill_reference_init_(module, seed=0):
+    """In-place deterministic init with the DISTRIBUTIONS of the reference's own constructors, in closed form (numpy legacy
+    RandomState, so the reference side in oracle/gen_golden*.py and the oracle / product side in tests/ hold bit-identical values
+    without a multi-MB weight fixture):
+      * 4-d weights (convolutions): N(0, 2 / (k_h k_w out_channels)) — `RetinaNet.__init__`, reference retinanet.py:327-330
+        (what torchvision's ResNet does as kaiming_normal_(mode='fan_out'));
+      * 2-d weights (linear layers): N(0, 2 / fan_in) — `initialize_modules(.., nn.init.kaiming_normal_)`, reference
+        General/Layers.py:137, General/Core.py:159-175; their biases 0 (Core.py:171);
+      * BatchNorm scale 1 and shift 0 (retinanet.py:331-333; torch's default for the head's BatchNorm1d);
+      * every other 1-d parameter (conv biases): 0."""
+    with torch.no_grad():
+        for j, (name, p) in enumerate(module.named_parameters()):
+            tag = 104729 * (seed + 1) + j
+            if p.dim() == 4:
+                p.copy_(torch.from_numpy(synth_array(p.shape, tag, (2.0 / (p.shape[0] * p.shape[2] * p.shape[3])) ** 0.5)))
+            elif p.dim() >= 2:
+                p.copy_(torch.from_numpy(synth_array(p.shape, tag, (2.0 / int(np.prod(p.shape[1:]))) ** 0.5)))
+            elif name.endswith('weight'):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    return module
+
+
+def curve_labels(n, tag, ncls=2):
+    return torch.from_numpy(np.random.RandomState(200003 + int(tag)).randint(0, ncls, size=(n,)).astype(np.int64))
+
+
+def fill_lm_reference_init_(net, seed=0):
+    """The reference LanguageModelNet's own init distributions in closed form: embedding ~ U(-0.1, 0.1) with the pad row 0
+    (reference Text.py:461-462), every LSTM weight / bias ~ U(-1/sqrt(H), 1/sqrt(H)) with H the layer's hidden size (torch's
+    nn.LSTM default, which `WeightDropLSTM1` keeps, Text.py:483-488); the decoder weight is tied to the embedding."""
+    with torch.no_grad():
+        seen = set()
+        for j, (name, p) in enumerate(net.named_parameters()):
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            # keyed by the parameter's NAME (the reference lists weight_hh_l0_raw last, other builds may not)
+            tag = (zlib.crc32(name.encode()) + 130003 * (seed + 1)) % (2 ** 32)
+            u = np.random.RandomState(tag).random_sample(tuple(p.shape)).astype(np.float32) * 2.0 - 1.0
+            if 'embed' in name:
+                p.copy_(torch.from_numpy(u * 0.1))
+                p[1].zero_()                                      # pad token 1
+            else:
+                H = p.shape[0] // 4
+                p.copy_(torch.from_numpy(u * (1.0 / H ** 0.5)))
+    return net
+
+
+def lm_stream(V, bs, length, tag):
+    "token stream [bs, length] ~ U{4..V-1} (SURVEY.md §8d config 4), numpy legacy RandomState"
+    return np.random.RandomState(300007 + int(tag)).randint(4, V, size=(bs, length)).astype(np.int64)
+
+
+def detection_targets(N, M, S, K, tag):
+    """SURVEY.md §8d config 5 targets in closed form: per image m ~ U{1..M} boxes, x0,y0 ~ U(0, 0.58 S), w,h ~ U(0.06 S, 0.41 S)
+    (clipped to the image), classes ~ U{0..K-1}; padded with -1 to [N,M,4] / [N,M]."""
+    rs = np.random.RandomState(400009 + int(tag))
+    boxes = -np.ones((N, M, 4), np.float32)
+    cats = -np.ones((N, M), np.int64)
+    for i in range(N):
+        m = int(rs.randint(1, M + 1))
+        xy = rs.uniform(0, 0.58 * S, size=(m, 2))
+        wh = rs.uniform(0.06 * S, 0.41 * S, size=(m, 2))
+        b = np.concatenate([xy, np.minimum(xy + wh, S - 1.0)], 1)
+        boxes[i, :m] = np.round(b).astype(np.float32)
+        cats[i, :m] = rs.randint(0, K, size=m)
+    return boxes, cats
+
+
+def curve_batch_images(N, S, tag, amp=0.5):
+    """One LEARNABLE synthetic image minibatch for the loss-curve fixtures: 0.5 N(0,1) noise, labels ~ U{0,1}, and the label
+    written into channel 0 as a +-amp offset — so a 20-step curve actually descends (pure noise with random labels gives a
+    flat, maximally ill-conditioned one)."""
+    x, y = synth_input((N, 3, S, S), tag), curve_labels(N, tag)
+    x = x * 0.5
+    x[:, 0] += amp * (2.0 * y.float() - 1.0).view(-1, 1, 1)
+    return x, y

@@ -40,6 +40,10 @@ CASES = [
     (16, 256, 16, 16, 256, 3, 1, 1, True, True),    # ... at the benchmark's 16 images
     (16, 256, 8, 8, 256, 3, 1, 1, True, True),
     (16, 256, 4, 4, 256, 3, 1, 1, True, True),
+    (2, 256, 16, 16, 180, 3, 1, 1, True, 2),        # classification output conv with the SIGMOID in the epilogue (retinanet.py:286)
+    (16, 256, 8, 8, 180, 3, 1, 1, True, 2),
+    (1, 256, 64, 64, 180, 3, 1, 1, True, 2),
+    (3, 32, 9, 7, 24, 3, 1, 1, True, 2),
 ]
 
 
@@ -55,7 +59,7 @@ def test_conv2d_fwd_bwd(case):
     bc = b.clone().requires_grad_(True) if has_bias else None
     ref = F.conv2d(xc, wc, bc, stride=stride, padding=pad)
     if relu:
-        ref = F.relu(ref)
+        ref = torch.sigmoid(ref) if relu == 2 else F.relu(ref)
     dy = torch.randn(ref.shape, generator=g)
     ref.backward(dy)
 
@@ -70,6 +74,29 @@ def test_conv2d_fwd_bwd(case):
     assert_close(wg.grad, wc.grad, rtol=1e-4, atol=1e-5 * wc.grad.abs().max().item(), msg='dw')
     if has_bias:
         assert_close(bg.grad, bc.grad, rtol=1e-4, atol=1e-5 * bc.grad.abs().max().item(), msg='db')
+
+
+@pytest.mark.parametrize('N,C,h,w,K,bias', [(2, 1024, 16, 16, 256, True), (16, 512, 32, 32, 256, True), (1, 64, 3, 5, 32, False)])
+def test_conv_add_upsampled_is_the_fpn_merge(N, C, h, w, K, bias):
+    """`P5_upsampled + P4_1(C4)` (reference PyramidFeatures.forward, retinanet.py:131-141) in the lateral 1x1 convolution's
+    epilogue: forward and all four gradients (x, weight, bias, the small map) against torch's conv2d + nn.Upsample + add."""
+    from neuralnetworklibrary_amd import ops
+    g = torch.Generator().manual_seed(N * 7 + C)
+    x = torch.randn(N, C, 2 * h, 2 * w, generator=g)
+    wt = torch.randn(K, C, 1, 1, generator=g) / C ** 0.5
+    b = torch.randn(K, generator=g) if bias else None
+    small = torch.randn(N, K, h, w, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, wt, small)] + ([b.clone().requires_grad_(True)] if bias else [None])
+    ref = F.conv2d(leaves[0], leaves[1], leaves[3]) + torch.nn.Upsample(scale_factor=2, mode='nearest')(leaves[2])
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    dev = [t.to(DEV).requires_grad_(True) for t in (x, wt, small)] + ([b.to(DEV).requires_grad_(True)] if bias else [None])
+    out = ops.conv_add_upsampled(dev[0], dev[1], dev[3], dev[2])
+    out.backward(dy.to(DEV))
+    assert_close(out, ref, rtol=1e-4, atol=1e-5 * ref.abs().max().item(), msg='y')
+    for name, a, r in zip(('dx', 'dw', 'dsmall', 'db'), dev, leaves):
+        if a is not None:
+            assert_close(a.grad, r.grad, rtol=1e-4, atol=1e-5 * r.grad.abs().max().item(), msg=name)
 
 
 def test_conv2d_linearity_full_size():

@@ -221,6 +221,9 @@ def test_g12_objectdetectionnet_hip_vs_reference():
                                                 normwise=True, host32=osd[n].grad.reshape(-1)[:1024])
 
 
+FLOORED_TENSORS = ('regressor.',)          # see the end of the test below
+
+
 @pytest.mark.gpu
 def test_objectdetectionnet_full_baseline_size_vs_oracle_fp64():
     """BASELINE configs[4] assembled at its own image size — ObjectDetectionNet(20): ResNet-50 Bottleneck body + FPN + shared
@@ -276,8 +279,109 @@ def test_objectdetectionnet_full_baseline_size_vs_oracle_fp64():
     for i, ((n, pp), (_, p64)) in enumerate(zip(net.named_parameters(), o64.named_parameters())):
         g64, gp = p64.grad, pp.grad.detach().cpu().double()
         rows.append((n, (gp - g64).norm().item(), max((smp[i] - g64).norm().item() for smp in samples), g64.norm().item()))
-    q90 = float(np.quantile([e_cpu / max(ref, 1e-300) for _, _, e_cpu, ref in rows], 0.9))      # ... and never below the run's own spread
+    # the run's own spread (q90 of the envelope over all tensors) is a floor ONLY for the tensors whose gradient
+    # lives on the ~100 positive anchors of the batch — the box-regression tower (`regressor.*`: smooth-L1 is summed over positives
+    # only, Vision.py:1532-1566) — where one gate flip shows as 1e-2 whatever the tensor's own five-sample envelope happened to
+    # draw.  Every other tensor (backbone, FPN, classifier tower: gradients averaged over 49 104 anchors x 20 classes) must sit
+    # within 3x its OWN envelope + 1e-3.
+    q90 = float(np.quantile([e_cpu / max(ref, 1e-300) for _, _, e_cpu, ref in rows], 0.9))
+    bad = []
     for n, e_hip, e_cpu, ref in rows:
-        assert e_hip <= 3 * max(e_cpu, q90 * ref) + 1e-3 * ref, '%s: |hip-f64| %.3e vs max |cpu32-f64| %.3e (|f64| %.3e, q90 %.2e)' % (n, e_hip, e_cpu, ref, q90)
+        floor = q90 * ref if n.startswith(FLOORED_TENSORS) else 0.0
+        if not e_hip <= 3 * max(e_cpu, floor) + 1e-3 * ref:
+            bad.append('%s: |hip-f64| %.3e vs max |cpu32-f64| %.3e (|f64| %.3e, rel %.2e / %.2e)' % (n, e_hip, e_cpu, ref, e_hip / max(ref, 1e-300), e_cpu / max(ref, 1e-300)))
     print('worst relative gradient error vs fp64: hip %.2e, cpu32 envelope %.2e (q90 %.2e)' % (
         max(e / max(r, 1e-300) for _, e, _, r in rows), max(e / max(r, 1e-300) for _, _, e, r in rows), q90))
+    assert not bad, '%d tensors outside 3x their own fp32 envelope + 1e-3:\n%s' % (len(bad), '\n'.join(bad))
+
+
+def _g15_net_and_loss(g):
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    from oracle import synth
+    torch.manual_seed(0)
+    net = synth.fill_detection_net_(V.ObjectDetectionNet(int(g['K'])), seed=int(g['init_seed'])).to(DEV).train()
+    assert [n for n, _ in net.named_parameters()] == [str(s) for s in g['param_names']]
+    return net, V.SSD_loss(0.5, 0.25, 2.0)
+
+
+def _g15_batch(g, tag):
+    from oracle import synth
+    N, S, K, M = int(g['N']), int(g['S']), int(g['K']), int(g['M'])
+    boxes, cats = synth.detection_targets(N, M, S, K, tag)
+    return synth.synth_input((N, 3, S, S), tag).to(DEV), [torch.from_numpy(boxes).to(DEV), torch.from_numpy(cats).to(DEV)]
+
+
+@pytest.mark.gpu
+def test_g15_objectdetectionnet_assembled_at_baseline_batch_16_vs_reference():
+    """VERDICT r2 missing #4 / next #1(b): the ASSEMBLED ObjectDetectionNet(20) + SSD_loss at BASELINE configs[4]'s own size —
+    512 x 512, bs 16 (the batch the bench times: planner choices depend on N), 49 104 anchors, BatchNorm in training mode — one
+    forward + backward of the HIP path against the REFERENCE's own run (golden G15, oracle/gen_golden_curves.py g15, fp32 and
+    fp64): loss and its two parts, per-pyramid-level activation checksums, strided activation samples, every parameter's
+    gradient norm, 1024-element gradient slices.  Criterion: |hip - f64| <= 3 |ref32 - f64| + 1e-3 |f64|."""
+    g = load_golden('g15_retinanet_bs16')
+    net, lf = _g15_net_and_loss(g)
+    x, y = _g15_batch(g, 1500)
+    anchors, reg, clas = net(x)
+    loss = lf([anchors, reg, clas], y)
+    loss.backward()
+    assert anchors.shape[0] == 49104 and reg.shape == (16, 49104, 4) and clas.shape == (16, 49104, 20)
+    got = torch.stack([loss.detach(), torch.as_tensor(float(lf.reg_loss), device=DEV), torch.as_tensor(float(lf.clas_loss), device=DEV)])
+    assert_within_reference_gap(got, g, 'a.loss', 'loss / reg_loss / clas_loss')
+    r, c = reg.detach().double(), clas.detach().double()
+    o, lv = 0, []
+    for l in range(3, 8):
+        n_l = (512 // 2 ** l) ** 2 * 9
+        lv.append(torch.stack([r[:, o:o + n_l].sum(), r[:, o:o + n_l].abs().sum(), c[:, o:o + n_l].sum(), (c[:, o:o + n_l] ** 2).sum()]))
+        o += n_l
+    lv = torch.stack(lv)
+    r32, r64 = g['a.level_sums.f32'], g['a.level_sums.f64']
+    # checksums: sums of ~1e6 terms; the plain `reg` sum cancels (|sum| << sum |.|), so its scale is the |.|-sum next to it
+    scale = np.stack([r64[:, 1], r64[:, 1], np.abs(r64[:, 2]), r64[:, 3]], 1)
+    err, gap = np.abs(lv.cpu().numpy() - r64), np.abs(r32 - r64)
+    assert (err <= 3 * gap + 1e-4 * scale).all(), 'per-level activation checksums: worst err/scale %.2e' % (err / scale).max()
+    assert_within_reference_gap(r.reshape(-1)[::397], g, 'a.reg_sample', 'reg activations (every 397th)')
+    assert_within_reference_gap(c.reshape(-1)[::1987], g, 'a.clas_sample', 'clas activations (every 1987th)')
+    n32, n64 = g['a.grad_norms.f32'], g['a.grad_norms.f64']
+    names = [str(s) for s in g['param_names']]
+    hip = np.array([0.0 if p.grad is None else p.grad.double().norm().item() for _, p in net.named_parameters()])
+    bad = ['%s: hip %.6e ref32 %.6e f64 %.6e' % (n, h, a, b) for n, h, a, b in zip(names, hip, n32, n64)
+           if not abs(h - b) <= 3 * abs(a - b) + 1e-3 * abs(b)]
+    print('gradient norms: worst rel |hip-f64| %.2e, worst rel |ref32-f64| %.2e' % (
+        (np.abs(hip - n64) / np.maximum(n64, 1e-300)).max(), (np.abs(n32 - n64) / np.maximum(n64, 1e-300)).max()))
+    assert not bad, '%d gradient norms outside 3x the reference gap + 1e-3:\n%s' % (len(bad), '\n'.join(bad))
+    sd = dict(net.named_parameters())
+    for n in [str(s) for s in g['slice_names']]:
+        if 'a.grad.%s.f32' % n in g:
+            gr = sd[n].grad
+            assert_within_reference_gap(gr.contiguous().reshape(-1)[:1024], g, 'a.grad.' + n, 'gradient slice ' + n, normwise=True)
+
+
+@pytest.mark.gpu
+def test_g15_retinanet_10_step_loss_curve_every_step_within_1e3():
+    """VERDICT r2 next #1(a), RetinaNet leg: 10 consecutive `train1minibatch` steps (SGD momentum 0.9, lr [1e-4, 3e-4, 1e-3], wd 1e-4,
+    10 distinct batches of 16 images with 1-8 boxes each) at 512 x 512 against the REFERENCE's own Learner (golden G15; its fp32 and
+    fp64 runs stay within 3e-4 on every step): |hip - ref32| <= 1e-3 |ref32| on EVERY step."""
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    g = load_golden('g15_retinanet_bs16')
+    r32, r64 = g['losses.f32'], g['losses.f64']
+    assert (np.abs(r32 - r64) / np.abs(r64)).max() < 3e-4
+    net, lf = _g15_net_and_loss(g)
+
+    class D:
+        bs, target_type = int(g['N']), 'bbox'
+    d = D(); d.train_dl = [(None, [torch.zeros(16)])]; d.val_dl = d.train_dl
+    learner = Learner('/tmp/nnl_test_g15', d, net, optimizer='SGD_Mom', loss_func=lf)
+    learner.init_optimizer(wd=float(g['wd']))
+    lr = [float(v) for v in g['lr']]
+    losses = []
+    for i in range(int(g['steps'])):
+        x, y = _g15_batch(g, 1501 + i)
+        losses.append(learner.train1minibatch(x, y, lr))
+    losses = np.array(losses)
+    rel32 = np.abs(losses - r32) / np.abs(r32)
+    print('losses         ', np.array2string(losses, precision=5))
+    print('rel |hip-ref32|', np.array2string(rel32, precision=1))
+    print('rel |ref32-f64|', np.array2string(np.abs(r32 - r64) / np.abs(r64), precision=1))
+    assert (rel32 <= 1e-3).all(), 'step losses off the reference fp32 curve: worst %.2e at step %d' % (rel32.max(), rel32.argmax())
+    abs_sums = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()])
+    assert_close(abs_sums, g['after.abs_sums.f32'], 1e-3, 1e-6, 'parameter |.|-sums after the 10 steps vs the reference fp32 run')

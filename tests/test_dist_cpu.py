@@ -42,7 +42,7 @@ class _Data:
         self.train_dl, self.val_dl, self.bs = batches, batches, bs
 
 
-def _fit(rank, world, port, q, last=6, n_batches=5, hint=True, dropout=0.0):
+def _fit(rank, world, port, q, last=6, n_batches=5, hint=True, dropout=0.0, bs64=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch.distributed as dist
     from neuralnetworklibrary_amd import dist as nd
@@ -53,11 +53,12 @@ def _fit(rank, world, port, q, last=6, n_batches=5, hint=True, dropout=0.0):
     Learner.verbose = False
     if world > 1:
         nd.init_from_env('gloo')
-    batches = _batches(n_batches, 8, last)
+    gbs = 64 if bs64 else 8
+    batches = _batches(n_batches, gbs, last)
     shard = nd.ShardedBatches(batches, rank, world)
     if not hint:
         shard = list(shard)          # plain pre-cut batches: no dp_info -> the Learner agrees on the batch size by all-reduce
-    data = _Data(shard, 8 // world)
+    data = _Data(shard, gbs // world)
     net = _model(dropout=dropout)
     learner = Learner('/tmp/nnl_dist_test_%d_%d' % (world, rank), data, net, optimizer='Adam')
     if dropout:
@@ -213,3 +214,84 @@ def test_gradsync_equals_global_batch_gradient():
             assert g is None
         else:
             np.testing.assert_allclose(g, p.grad.numpy(), rtol=1e-5, atol=1e-7)
+
+
+# ---- world size 8: the shape of the driver's N = 8 run -------------------------------------------------
+def test_eight_ranks_global_batch_64_with_ragged_last_batch_61():
+    """BASELINE's strong-scaling shape rehearsed on gloo: global minibatch 64 over 8 ranks (8 rows each), ragged LAST batch of 61 =
+    8+8+8+8+8+7+7+7 (dist.shard_bounds), lr scaled by 61/64 on every rank, gradients weighted by local / global rows — final
+    weights equal the single-process run on the same global minibatches."""
+    _, w1 = _run(1, n_batches=3, last=61, bs64=True)
+    _, w8 = _run(8, n_batches=3, last=61, bs64=True)
+    np.testing.assert_allclose(w8, w1, rtol=2e-5, atol=2e-6)
+
+
+class _TinyLM(nn.Module):
+    """a language model with the product LSTM_Encoder's state semantics (Text.py:535-551): hidden state carried across
+    minibatches per STREAM (dim 0 of the batch), detached after every forward, never reset by the Learner"""
+
+    def __init__(self, V=23, E=6, H=10, bs=64):
+        super().__init__()
+        self.emb, self.lstm, self.dec = nn.Embedding(V, E), nn.LSTM(E, H), nn.Linear(H, V)
+        self.h, self.c = torch.zeros(1, bs, H), torch.zeros(1, bs, H)
+
+    def forward(self, x):                                   # x [bs, seq]
+        out, (h, c) = self.lstm(self.emb(x.t()), (self.h, self.c))
+        self.h, self.c = h.detach(), c.detach()
+        return self.dec(out).permute(1, 2, 0)               # [bs, V, seq]
+
+
+def _lm_fit(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.General.Core import make_model_basic, set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device('cpu')
+    torch.set_num_threads(1)
+    Learner.verbose = False
+    if world > 1:
+        nd.init_from_env('gloo')
+    bs, seq, V = 64, 5, 23
+    stream = np.random.RandomState(7).randint(0, V, size=(bs, 3 * seq + 1)).astype(np.int64)
+    batches = [(torch.from_numpy(stream[:, i * seq:(i + 1) * seq].copy()), torch.from_numpy(stream[:, i * seq + 1:(i + 1) * seq + 1].copy()))
+               for i in range(3)]                           # three CONSECUTIVE windows of the 64 streams
+    torch.manual_seed(0)
+    net = make_model_basic(_TinyLM(V, bs=bs // world))
+    data = _Data(nd.ShardedBatches(batches, rank, world), bs // world)
+    data.val_dl = []                                        # (a validation pass would advance the carried state: Learner never resets it)
+    data.target_type = 'lang_model'
+    learner = Learner('/tmp/nnl_dist_lm_%d_%d' % (world, rank), data, net, optimizer='Adam', loss_func=nn.CrossEntropyLoss())
+    learner.evaluate = lambda *a, **k: [0.0]
+    if world > 1:
+        learner.distribute(bucket_mb=0.001, equal_shards=True)
+    learner.fit(1e-2, 1, wd=1e-4)
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    q.put((rank, flat.numpy(), net.h.numpy().copy(), net.c.numpy().copy()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_lm_stream_sharding_64_over_8_keeps_the_carried_state_rank_local():
+    """SURVEY §8e / Text.py:254-263,531-551: the language model's minibatch is split along the STREAM dimension (64 streams over 8
+    ranks = 8 each), every rank keeps its own streams and their carried (h, c) from batch to batch.  After three consecutive
+    minibatches the weights equal the 1-rank run and rank r's carried state equals rows [8r, 8r+8) of the 1-rank state."""
+    def run(world):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_lm_fit, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        return got
+    (_, w1, h1, c1), = run(1)
+    got8 = run(8)
+    for r, w, h, c in got8:
+        np.testing.assert_allclose(w, w1, rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(h, h1[:, 8 * r:8 * r + 8], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(c, c1[:, 8 * r:8 * r + 8], rtol=2e-5, atol=2e-6)

@@ -70,3 +70,43 @@ def test_state_dict_round_trip_with_fused_state():
     o.opt.load_state_dict(sd)
     _, _, o2 = run('SGD_Mom', True, dict(wd=1e-3, clip=None), steps=2)
     assert 'momentum_buffer' in o2.opt.state_dict()['state'][0]
+
+
+@pytest.mark.parametrize('tag,opt,kw', [('sgd', 'SGD_Mom', dict(wd=[1e-2, 3e-2], bn_wd=True, clip=0.5)),
+                                        ('adam', 'Adam', dict(wd=1e-2, bn_wd=False, clip=None))])
+def test_fused_step_against_the_reference_g9(tag, opt, kw):
+    """a DIRECT oracle pin of the fused kernel — the parameters after three `Optimizer.step`s of the REFERENCE
+    (golden G9, oracle/gen_golden.py g9: decoupled wd per layer group, bn_wd on / off, global-norm clip, SGD-momentum and Adam)
+    against the product Optimizer on the GPU with the multi-tensor HIP kernel (nnl_optim_step), same toy model and batch."""
+    from conftest import load_golden
+    from oracle import synth
+    from neuralnetworklibrary_amd.General.Core import separate_bn_layers
+    from neuralnetworklibrary_amd.General.Learner import opt_dict
+    from neuralnetworklibrary_amd.General.Optimizer import Optimizer
+    g = load_golden('g9_host_logic')
+    def toy9():
+        g1 = nn.Sequential(nn.Linear(5, 7), nn.BatchNorm1d(7), nn.Tanh())
+        g2 = nn.Sequential(nn.Linear(7, 1), nn.Flatten(0))
+        net = nn.Sequential(g1, g2)
+        synth.fill_module_(net, seed=11)
+        net.layer_groups = [g1, g2]
+        net.param_groups = separate_bn_layers(net.layer_groups)
+        return net
+    net, host = toy9().to(DEV), toy9()
+    o = Optimizer(opt_dict[opt], net)
+    o.set_params([1e-1, 3e-1], **kw)
+    X, Y = torch.from_numpy(g['X']), torch.from_numpy(g['Y'])
+    for _ in range(3):
+        # the GRADIENTS come from torch on the host (as in the golden run), so that the comparison isolates Optimizer.step: the
+        # Linear before a BatchNorm has near-zero gradient components whose rounding Adam's g / sqrt(v) amplifies to O(lr) —
+        # gradients computed by another device's kernels would differ there by 1e-4 relative and say nothing about the optimizer
+        host.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+        host.zero_grad()
+        ((host(X[:8]) - Y[:8]) ** 2).mean().backward()
+        o.opt.zero_grad()
+        for p, h in zip(net.parameters(), host.parameters()):
+            p.grad = h.grad.to(DEV)
+        o.step()
+    assert o._fused is not None and o._fused is not False, 'the fused HIP optimizer did not run'
+    for n, p in net.named_parameters():
+        assert_close(p, g['opt.%s.%s' % (tag, n)], 2e-5, 2e-7, n)

@@ -301,3 +301,143 @@ def test_language_model_full_baseline_size_vs_oracle_fp64():
         assert_close(net.enc.h[i], o64.enc.h[i].float(), 1e-3, 1e-5, 'carried h%d' % i)
         assert_close(net.enc.c[i], o64.enc.c[i].float(), 1e-3, 1e-5, 'carried c%d' % i)
     print('worst relative gradient error vs fp64: %.2e' % worst)
+
+
+def _g14_batches(g, dev):
+    V, bs, bptt, steps = int(g['V']), int(g['bs']), int(g['bptt']), int(g['steps'])
+    stream = synth.lm_stream(V, bs, steps * bptt + 1, 14)
+    return [(torch.from_numpy(stream[:, i * bptt:(i + 1) * bptt].copy()).to(dev), torch.from_numpy(stream[:, i * bptt + 1:(i + 1) * bptt + 1].copy()).to(dev))
+            for i in range(steps)]
+
+
+@pytest.mark.gpu
+def test_g14_language_model_20_step_loss_curve_every_step_within_1e3():
+    """20 consecutive `train1minibatch` steps of the product Learner at BASELINE configs[3]'s own size
+    (400 / 1150 / 3, V = 47 343, bs 64, bptt 70, Adam betas (0.8, 0.99), lr [5e-4, 1e-3], wd 1e-6, RegSeqCrossEntropyLoss(2, 1),
+    dropout 0, hidden state carried over 20 consecutive windows of one token stream) against the REFERENCE's own Learner on the
+    same closed-form init and tokens (golden G14, oracle/gen_golden_curves.py; the reference's fp32 and fp64 runs stay within
+    3e-4 of each other on every step).  |hip - ref32| <= 1e-3 |ref32| on EVERY step."""
+    from neuralnetworklibrary_amd.Applications.Text import LanguageModelNet, RegSeqCrossEntropyLoss, _Vocab
+    from neuralnetworklibrary_amd.General.Learner import Learner, opt_dict
+    from neuralnetworklibrary_amd.General.Optimizer import Optimizer
+    from functools import partial
+    g = load_golden('g14_lm_curve')
+    V, bs = int(g['V']), int(g['bs'])
+    r32, r64 = g['losses.f32'], g['losses.f64']
+    assert (np.abs(r32 - r64) / np.abs(r64)).max() < 3e-4
+    stoi = {i: i for i in range(V)}
+    stoi['_pad_'] = 1
+    del stoi[1]
+    d = _Vocab(stoi, bs)
+    d.target_type = 'lang_model'
+    net = LanguageModelNet(d, enc_drops=[0., 0., 0., 0.], dec_drop=0.)
+    net.clear_non_raw()
+    synth.fill_lm_reference_init_(net, seed=int(g['init_seed']))
+    assert sorted(n for n, _ in net.named_parameters()) == sorted(str(s) for s in g['param_names'])
+    net = net.to(DEV)
+    batches = _g14_batches(g, DEV)
+    d.train_dl, d.val_dl = batches[:1], batches[:1]
+    opt = Optimizer(partial(torch.optim.Adam, betas=(0.8, 0.99)), net)
+    learner = Learner('/tmp/nnl_test_g14', d, net, opt, RegSeqCrossEntropyLoss(2.0, 1.0))
+    learner.init_optimizer(wd=float(g['wd']))
+    net.train()
+    lr = [float(v) for v in g['lr']]
+    losses = np.array([learner.train1minibatch(x, y, lr, betas_batch=(0.8, 0.99)) for x, y in batches])
+    rel32 = np.abs(losses - r32) / np.abs(r32)
+    print('losses         ', np.array2string(losses, precision=4))
+    print('rel |hip-ref32|', np.array2string(rel32, precision=1))
+    print('rel |hip-f64|  ', np.array2string(np.abs(losses - r64) / np.abs(r64), precision=1))
+    print('rel |ref32-f64|', np.array2string(np.abs(r32 - r64) / np.abs(r64), precision=1))
+    assert (rel32 <= 1e-3).all(), 'step losses off the reference fp32 curve: worst %.2e at step %d' % (rel32.max(), rel32.argmax())
+    by_name = dict(zip([str(s) for s in g['param_names']], g['after.abs_sums.f32']))
+    for n, p in net.named_parameters():
+        assert_close(np.array([p.double().abs().sum().item()]), np.array([by_name[n]]), 1e-3, 1e-6, '|.|-sum of %s after the 20 steps' % n)
+
+
+def test_g14_oracle_first_steps_at_baseline_size():
+    """the CPU oracle (restated LM + restated Optimizer.step, Adam) reproduces the first 2 steps of the reference's G14 curve at
+    BASELINE configs[3]'s own size, state carried from the first window to the second"""
+    g = load_golden('g14_lm_curve')
+    V, bs = int(g['V']), int(g['bs'])
+    torch.set_num_threads(min(torch.get_num_threads(), 16))
+    net = RT.LanguageModelNet(V, 1, bs)
+    synth.fill_lm_reference_init_(net, seed=int(g['init_seed']))
+    net.train()
+    names = [n for n, _ in net.named_parameters()]
+    params = [p for _, p in net.named_parameters()]
+    lrs = [float(g['lr'][lm_group_of(n)]) for n in names]
+    state = RM.OptimState(params)
+    E, H = 400, 1150
+    sizes = [E, H, H, E]
+    ones = {'emb_rows': torch.ones(V, 1), 'emb_locked': torch.ones(1, bs, E), 'weights': [torch.ones(4 * sizes[i + 1], sizes[i + 1]) for i in range(3)],
+            'hidden': [torch.ones(1, bs, sizes[i + 1]) for i in range(3)]}
+    for i, (x, y) in enumerate(_g14_batches(g, 'cpu')[:2]):
+        for p in params:
+            p.grad = None
+        loss = RT.reg_seq_cross_entropy(net(x, ones, torch.ones(1, bs, E)), y, 2.0, 1.0)[0]
+        loss.backward()
+        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [float(g['wd'])] * len(params), 'adam', betas=(0.8, 0.99))
+        assert abs(loss.item() - g['losses.f32'][i]) <= 5e-5 * abs(g['losses.f32'][i]), (i, loss.item(), g['losses.f32'][i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,B,E,alpha,beta', [(70, 64, 400, 2.0, 1.0), (5, 3, 7, 0.5, 3.0), (1, 4, 8, 2.0, 1.0), (9, 2, 16, 0.0, 1.0)])
+def test_seq_activation_reg_vs_torch(T, B, E, alpha, beta):
+    """the AR / TAR terms of RegSeqCrossEntropyLoss (reference Text.py:775-776) on one HIP reduction kernel: value and gradient
+    against torch's `alpha * h.pow(2).mean() + beta * (h[1:] - h[:-1]).pow(2).mean()` in fp64"""
+    from neuralnetworklibrary_amd import ops
+    g = torch.Generator().manual_seed(T * 100 + B)
+    h = torch.randn(T, B, E, generator=g)
+    h64 = h.double().requires_grad_(True)
+    ref = alpha * h64.pow(2).mean() + (beta * (h64[1:] - h64[:-1]).pow(2).mean() if T > 1 else 0.0)
+    (3.0 * ref).backward()
+    hd = h.to(DEV).requires_grad_(True)
+    out = ops.seq_activation_reg(hd, alpha, beta)
+    (3.0 * out).backward()
+    assert_close(out.reshape(1), np.array([float(ref)]), 1e-5, 1e-7, 'value')
+    assert_close(hd.grad, h64.grad.float(), 1e-5, 1e-6 * h64.grad.abs().max().item(), 'dh')
+    a = ops.seq_activation_reg(hd.detach(), alpha, beta)
+    assert torch.equal(a, ops.seq_activation_reg(hd.detach(), alpha, beta))            # fixed-order sums: reproducible
+
+
+@pytest.mark.gpu
+def test_weight_drop_kernel_masks_pads_and_is_its_own_backward():
+    """nnl_weight_drop (WeightDropLSTM1's `Dropout_p(W_raw)`, Text.py:511, fused with the padding of W_hh): (1) an explicit mask
+    reproduces raw * mask with zero pad columns, bit for bit; (2) a generated mask is Bernoulli(1 - p) / (1 - p), the SAME for the
+    same seed (so the backward call re-derives the forward's mask) and different for another; (3) through the LSTM layer the
+    gradient of the raw matrix is dW * mask."""
+    from neuralnetworklibrary_amd import ops_text
+    from neuralnetworklibrary_amd._lib import check, lib, ptr, stream
+    G, H, Hp, p = 4 * 50, 50, 64, 0.3
+    g = torch.Generator().manual_seed(4)
+    raw = torch.randn(G, H, generator=g).to(DEV)
+    mask = ((torch.rand(G, H, generator=g) >= p).float() / (1 - p)).to(DEV)
+    out = torch.full((G, Hp), float('nan'), device=DEV)
+    check(lib.nnl_weight_drop(ptr(raw), H, ptr(mask), ptr(out), Hp, G, H, 0, 0.0, stream()))
+    assert torch.equal(out[:, :H], raw * mask) and float(out[:, H:].abs().sum()) == 0.0
+    outs = []
+    for seed in (123, 123, 124):
+        o = torch.empty(G, Hp, device=DEV)
+        check(lib.nnl_weight_drop(ptr(raw), H, None, ptr(o), Hp, G, H, seed, p, stream()))
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+    m = outs[0][:, :H] / raw
+    keep = (m != 0)
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.02
+    assert_close(m[keep], torch.full_like(m[keep], 1 / (1 - p)), 1e-5, 0, 'kept elements are scaled by 1 / (1 - p)')
+    back = torch.empty(G, H, device=DEV)                      # the backward call: padded source, dense destination, same seed
+    check(lib.nnl_weight_drop(ptr(outs[0]), Hp, None, ptr(back), H, G, H, 123, p, stream()))
+    assert_close(back, raw * m * m, 1e-5, 1e-6, 'the backward call applies the same mask')
+    # through the layer, explicit mask: d raw = (d of the dropped matrix) * mask
+    T, B, I = 4, 3, 6
+    x = torch.randn(T, B, I, generator=g).to(DEV)
+    w_ih, b1, b2 = torch.randn(G, I, generator=g).to(DEV) * 0.3, torch.randn(G, generator=g).to(DEV) * 0.1, torch.zeros(G, device=DEV)
+    h0 = c0 = torch.zeros(1, B, H, device=DEV)
+    r1 = (raw * 0.2).clone().requires_grad_(True)
+    y1, _ = ops_text.lstm_layer(x, h0, c0, w_ih, r1, b1, b2, weight_mask=mask)
+    y1.sum().backward()
+    r2 = (raw * 0.2 * mask).clone().requires_grad_(True)       # the dropped matrix as a leaf, no mask
+    y2, _ = ops_text.lstm_layer(x, h0, c0, w_ih, r2, b1, b2)
+    y2.sum().backward()
+    assert torch.equal(y1, y2)
+    assert_close(r1.grad, r2.grad * mask, 1e-6, 1e-7, 'd raw = dW * mask')

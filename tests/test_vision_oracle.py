@@ -127,3 +127,29 @@ def test_g6_resnet34_oracle_forward_backward_and_step():
     abs_sums = np.array([p.double().abs().sum().item() for p in params])
     assert_close(abs_sums, g['after.abs_sums'], 1e-6, 1e-9, 'abs sums after step')
     assert_close(sums, g['after.sums'], 1e-5, 1e-5, 'sums after step')
+
+
+def test_g13b_oracle_first_steps_at_baseline_size():
+    """the CPU oracle (restated nets + restated Optimizer.step) reproduces the first 3 steps of the REFERENCE's own 20-step
+    curve at BASELINE configs[1]'s size (G13b: ResNet-34, 224 x 224, bs 64, SGD momentum, lr per layer group, wd)."""
+    import torch.nn as nn
+    from oracle import reference_math as RM, reference_nets as RNets
+    g = load_golden('g13b_resnet34_curve')
+    N, S = int(g['N']), int(g['S'])
+    onet = RNets.ImageClassificationNet(RNets.resnet34(), 2, 512, drops=(0., 0.), probe_sz=(S, S))
+    synth.fill_reference_init_(onet, seed=int(g['init_seed']))
+    onet.train()
+    names = [n for n, _ in onet.named_parameters()]
+    assert names == [str(s) for s in g['param_names']]
+    params = [p for _, p in onet.named_parameters()]
+    group = lambda n: 2 if n.startswith('head') else (0 if int(n.split('.')[1]) < 6 else 1)
+    lrs = [float(g['lr'][group(n)]) for n in names]
+    state = RM.OptimState(params)
+    for i in range(3):
+        x, y = synth.curve_batch_images(N, S, 1300 + i)
+        for p in params:
+            p.grad = None
+        loss = nn.CrossEntropyLoss()(onet(x), y)
+        loss.backward()
+        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [float(g['wd'])] * len(params), 'sgd')
+        assert abs(loss.item() - g['losses.f32'][i]) <= 2e-5 * abs(g['losses.f32'][i]), (i, loss.item(), g['losses.f32'][i])
