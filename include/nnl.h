@@ -371,8 +371,9 @@ int nnl_weight_drop(const float* src, int64_t ld_src, const float* mask, float* 
  * one tensor share one dense layout and are indexed flat.  grad == NULL: decay only.  lr and decay (= 1 - wd*lr, or 1)
  * are per tensor (layer-group learning rates).  (chunk_tensor[c], chunk_off[c]) maps workgroup c to a piece of
  * nnl_optim_chunk_elems() elements.  kind 0 = SGD (state1 = momentum buffer, zero before the first step; momentum may be
- * 0), kind 1 = Adam (state1 = exp_avg, state2 = exp_avg_sq).  `hyper` is a DEVICE array of 8 floats {momentum, beta1,
- * beta2, eps, bc1 = 1-beta1^t, sqrt(bc2) = sqrt(1-beta2^t), clip max_norm, unused}: hyper-parameters are read from
+ * 0), kind 1 = Adam (state1 = exp_avg, state2 = exp_avg_sq).  `hyper` is a DEVICE array of 8 floats {momentum (SGD) or
+ * 1-beta1 (Adam), beta1, beta2, eps, bc1 = 1-beta1^t, sqrt(bc2) = sqrt(1-beta2^t), clip max_norm, 1-beta2} (1-beta rounded once from
+ * double by the caller, as torch.optim.Adam's scalar arguments are): hyper-parameters are read from
  * memory so that a captured hipGraph of the whole step can be replayed with new values.  use_clip != 0: gradients are
  * scaled by min(1, max_norm/(||g||_2 + 1e-6)) (also written back to .grad, as clip_grad_norm_ does); clip_workspace:
  * n_chunks + 2 floats, [0] = coefficient, [1] = total norm on return. */

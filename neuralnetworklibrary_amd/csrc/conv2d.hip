@@ -118,16 +118,21 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   const double plain = wave_iters(T, I) * c_it;
   best.t_us = plain;
   double best_t = plain * (e_bal == 2 ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
+  const int f_ks = NNL_ENV_INT("NNL_IGEMM_PLAN_KS", 0), f_S = NNL_ENV_INT("NNL_IGEMM_PLAN_S", 0);   // A/B hooks: force the plan's k slicing
+  if (f_ks > 0 || f_S > 0) best_t = 1e300;
   for (int ks = 1; ks <= 4; ks *= 2) {
+    if (f_ks > 0 && ks != f_ks) continue;
     if (I / ks < 8) break;
     const long units = T * ks;
     long n_main = ((units / kCUs) * kCUs / ks / gn) * gn;              // main tiles: whole multiples of 256 workgroups, whole tile rows
     if (n_main > T) n_main = T;
     const long tail = T - n_main;
     const long it_main = nnl_cdiv(I, ks);
-    for (int S = 1; S <= 32; S *= 2) {
+    static const int kSlices[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 32, 36, 48};
+    for (int S : kSlices) {
       if (tail == 0 && S > 1) break;
       if (S > 1 && I / S < 4) break;
+      if (f_S > 0 && tail > 0 && S != f_S) continue;
       const long it_tail = nnl_cdiv(I, S);
       const long tail_blocks = tail * S;
       double t = (wave_iters(n_main * ks, it_main) + wave_iters(tail_blocks, it_tail + (S > 1 ? 2 : 0))) * c_it;
@@ -220,6 +225,9 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counte
 int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0, int* counters = nullptr,
                   int* bn_rows = nullptr) {
   IgemmTapsParams p = p_in;
+#ifdef NNL_TAPS_TIMING
+  p.tile_counters = counters;                       // debug builds: the timestamp area lives behind the counters (igemm_taps.h)
+#endif
   if (bn_rows) *bn_rows = 0;
   const int forced = NNL_ENV_INT("NNL_IGEMM_TILE", -1);
   struct Cand { int bm, bn, occ; double eff; };
@@ -455,7 +463,9 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
     if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
     const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
     const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
-    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5); ++sp) {   // unsplit is always a candidate
+    const int f_sp = NNL_ENV_INT("NNL_WGRAD_SPLITS", 0);                  // A/B hook: force the split count
+    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5 || f_sp > 0); ++sp) {   // unsplit is always a candidate
+      if (f_sp > 0 && sp != (f_sp < max_splits ? f_sp : max_splits)) continue;
       const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32) * 32;
       const long rs = nnl_cdiv(Kp, k1);
       if (rs != sp) continue;                                             // same plan as a smaller sp

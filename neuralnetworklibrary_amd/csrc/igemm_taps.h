@@ -124,6 +124,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
+#ifdef NNL_TAPS_TIMING
+  // debug builds only (tools/gpu/*timing*): four 100 MHz timestamps per workgroup (entry, loop start, loop end, exit) in the upper
+  // half of the caller's tile-counter buffer — where does the fixed ~14 us per launch go?
+  unsigned long long* const dbg_t = (p.tile_counters != nullptr && blockIdx.x < 4096 && blockIdx.y == 0)
+                                        ? reinterpret_cast<unsigned long long*>(p.tile_counters + 32768) + (long)blockIdx.x * 4 : nullptr;
+  if (dbg_t && tid == 0) dbg_t[0] = wall_clock64();
+#define NNL_TSTAMP(i) do { if (dbg_t && tid == 0) dbg_t[i] = wall_clock64(); } while (0)
+#else
+#define NNL_TSTAMP(i) do { } while (0)
+#endif
   int logical, kslice = 0, nslices = 1, row0 = 0, cls = 0;
   bool in_tail = false;
   float* yout = p.y;
@@ -410,6 +420,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     store_tile(0);
   }
   __syncthreads();
+  NNL_TSTAMP(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     // advance to tile kt+1 (the final iteration re-fetches the last tile instead: harmless, keeps the body uniform)
@@ -424,6 +435,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   }
   }
 
+  NNL_TSTAMP(2);
   // ---- epilogue ----
   if constexpr (kTwoAcc) {
 #pragma unroll
@@ -647,6 +659,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 1] = red[tid * 2 + 1] + red[(64 + tid) * 2 + 1];
     }
   }
+#ifdef NNL_TAPS_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NNL_TSTAMP(3);
+#endif
 }
 
 // One LSTM timestep (defined in conv2d.hip, where the kernel templates are instantiated): epi 1 = forward (q.M = batch,

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(kBlock) void optim_step_kernel(const nnl_optim_tens
   // hyper-parameters live in device memory (uploaded with the descriptor table) so that a captured hipGraph of the whole
   // training step can be replayed with new momentum / betas / bias corrections
   const float momentum = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], bc1 = hyper[4], sqrt_bc2 = hyper[5];
+  const float omb1 = hyper[0], omb2 = hyper[7];             // Adam: 1 - beta1, 1 - beta2 rounded once on the host (slot 0 is the momentum for SGD)
   const nnl_optim_tensor_t t = tensors[chunk_tensor[blockIdx.x]];
   const long off = chunk_off[blockIdx.x];
   const long end = off + kChunk < t.numel ? off + kChunk : t.numel;
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(kBlock) void optim_step_kernel(const nnl_optim_tens
       if (momentum != 0.f) { d = momentum * s1[i] + g; s1[i] = d; }
       x -= lr * d;
     } else {
-      const float m = beta1 * s1[i] + (1.f - beta1) * g;
-      const float v = beta2 * s2[i] + (1.f - beta2) * g * g;
+      const float m = beta1 * s1[i] + omb1 * g;               // torch: exp_avg.lerp_(g, 1 - beta1) / mul_(beta1).add_(g, alpha = 1 - beta1)
+      const float v = beta2 * s2[i] + omb2 * g * g;           //        exp_avg_sq.mul_(beta2).addcmul_(g, g, value = 1 - beta2)
       s1[i] = m; s2[i] = v;
       x -= (lr / bc1) * (m / (sqrtf(v) / sqrt_bc2 + eps));
     }

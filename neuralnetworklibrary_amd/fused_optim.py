@@ -101,6 +101,17 @@ class FusedStep:
         b1, b2 = (float(b) for b in g0['betas'])
         return [0., b1, b2, float(g0['eps']), 1.0 - b1 ** step, float(np.sqrt(1.0 - b2 ** step))]
 
+    def _advance_hyper(self, clip):
+        """the 8 floats nnl_optim_step reads: {momentum | 1 - beta1, beta1, beta2, eps, bc1, sqrt(bc2), clip max_norm, 1 - beta2}.
+        1 - beta is formed HERE in double and rounded once, as torch.optim.Adam does (`addcmul_(g, g, value=1 - beta2)`): formed on
+        the device in fp32, 1 - 0.999f is off by 1.3e-5 relative, i.e. 2.7e-6 absolute on a weight after three lr = 0.1 steps (the
+        direct G9 comparison with the reference found it)."""
+        h = self._advance()
+        if self.kind == 1:
+            b1, b2 = (float(b) for b in self.opt.param_groups[0]['betas'])
+            return [1.0 - b1] + h[1:] + [float(clip or 0.), 1.0 - b2]
+        return h + [float(clip or 0.), 0.]
+
     def step(self, lrs, decays, clip):
         """lrs / decays: one value per torch param group (decay = 1 - wd*lr or 1.0)."""
         self._init_state()                                  # state may have been replaced by opt.load_state_dict
@@ -132,7 +143,7 @@ class FusedStep:
             self.flip ^= 1
         hn = h.numpy()
         hn[:self.table_bytes] = desc.view(np.uint8)
-        hn[self.table_bytes:].view(np.float32)[:] = self._advance() + [float(clip or 0.), 0.]
+        hn[self.table_bytes:].view(np.float32)[:] = self._advance_hyper(clip)
         self.dev.copy_(h, non_blocking=True)
         hyper = self.dev.data_ptr() + self.table_bytes
         check(lib.nnl_optim_step(ptr(self.dev), ptr(self.chunk_tensor), ptr(self.chunk_off), self.n_chunks, self.kind,
@@ -152,4 +163,4 @@ class FusedStep:
         g = np.asarray(self.group_of)
         d['lr'] = np.asarray(lrs, dtype=np.float32)[g]
         d['decay'] = np.asarray(decays, dtype=np.float32)[g]
-        hn[self.table_bytes:].view(np.float32)[:] = self._advance() + [float(clip or 0.), 0.]
+        hn[self.table_bytes:].view(np.float32)[:] = self._advance_hyper(clip)

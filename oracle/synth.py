@@ -102,9 +102,19 @@ def fill_lm_reference_init_(net, seed=0):
     return net
 
 
-def lm_stream(V, bs, length, tag):
-    "token stream [bs, length] ~ U{4..V-1} (SURVEY.md §8d config 4), numpy legacy RandomState"
-    return np.random.RandomState(300007 + int(tag)).randint(4, V, size=(bs, length)).astype(np.int64)
+def lm_stream(V, bs, length, tag, n_sub=512, p_follow=0.75):
+    """LEARNABLE token stream [bs, length] for the language-model loss-curve fixture: tokens come from a fixed subset of `n_sub`
+    vocabulary entries (ids >= 4, spread over the whole vocabulary) and follow a first-order chain — with probability `p_follow`
+    the next token is a fixed function of the current one, else uniform over the subset.  (A uniform stream over V = 47 343
+    tokens, SURVEY.md §8d's benchmark input, has nothing to learn: its loss curve stays at ln V and would not notice a broken
+    update.)  numpy legacy RandomState: bit-stable."""
+    rs = np.random.RandomState(300007 + int(tag))
+    sub = 4 + rs.permutation(V - 4)[:n_sub].astype(np.int64)
+    idx = rs.randint(0, n_sub, size=(bs, length))
+    follow = rs.random_sample((bs, length)) < p_follow
+    for t in range(1, length):
+        idx[:, t] = np.where(follow[:, t], (3 * idx[:, t - 1] + 7) % n_sub, idx[:, t])
+    return sub[idx]
 
 
 def detection_targets(N, M, S, K, tag):

@@ -109,4 +109,9 @@ def test_fused_step_against_the_reference_g9(tag, opt, kw):
         o.step()
     assert o._fused is not None and o._fused is not False, 'the fused HIP optimizer did not run'
     for n, p in net.named_parameters():
+        if tag == 'adam' and n == '0.0.bias':
+            # the bias of a Linear that feeds a BatchNorm has a THEORETICALLY ZERO gradient: what autograd returns is ~1e-9 of
+            # rounding noise whose sign depends on the host's BLAS path, and Adam's g / sqrt(v) turns any sign into a full +-lr step
+            # (got -0.133 vs 0.154 on the GPU box's CPU against the build container's).  Not a statement about the optimizer.
+            continue
         assert_close(p, g['opt.%s.%s' % (tag, n)], 2e-5, 2e-7, n)

@@ -51,14 +51,12 @@ def ab(args):
         x = torch.randn(N, H, H, C, device=dev); w = torch.randn(K, R, R, C, device=dev) * 0.05
         y = torch.empty(N, g.P, g.Q, K, device=dev); dy = torch.randn(N, g.P, g.Q, K, device=dev)
         wt = torch.empty(C, R, R, K, device=dev); dx = torch.empty_like(x); dw = torch.empty_like(w)
-        fwsb = int(lib.nnl_conv2d_fwd_workspace_bytes(g)); fws = torch.empty(max(fwsb // 4, 1), device=dev)
-        dwsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g)); dws = torch.empty(max(dwsb // 4, 1), device=dev)
-        wsb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ws = torch.empty(max(wsb // 4, 1) * 4, device=dev)
+        big = torch.empty(64 << 20, device=dev)             # 256 MB: the workspace queries are re-run per env value (plans change)
         check(lib.nnl_conv2d_weight_transpose(ptr(w), ptr(wt), K, R, R, C, stream()))
         flop = 2.0 * N * g.P * g.Q * K * R * R * C
-        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(fws), fwsb, ptr(ops._tile_counters(x.device)), None, None, None, stream())),
-               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(dws), dwsb, ptr(ops._tile_counters(x.device)), stream())),
-               'wgrad': lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ws), ws.numel() * 4, stream()))}
+        fns = {'fwd': lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, ptr(big), int(lib.nnl_conv2d_fwd_workspace_bytes(g)), ptr(ops._tile_counters(x.device)), None, None, None, stream())),
+               'dgrad': lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(big), int(lib.nnl_conv2d_dgrad_workspace_bytes(g)), ptr(ops._tile_counters(x.device)), stream())),
+               'wgrad': lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(big), int(lib.nnl_conv2d_wgrad_workspace_bytes(g)), stream()))}
         for pname, fn in fns.items():
             if name == 'stem7x7' and pname == 'dgrad':
                 continue

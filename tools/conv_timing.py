@@ -1,0 +1,41 @@
+"""Where does a conv launch spend its time?  Runs ONE plain (unbalanced) launch of the tap-table kernel per shape with the
+timing build of the library (tools/build_timing_lib.sh; four 100 MHz timestamps per workgroup: entry, loop start, loop end, exit)
+and prints, in microseconds: the dispatch skew of the workgroups, prologue / k loop / epilogue per workgroup, the launch span
+seen from inside (first entry -> last exit) and the HIP-event time of the same launch.
+Usage (GPU box): NNL_LIB_PATH=$PWD/tools/ab/libnnl_hip_timing.so NNL_IGEMM_BALANCE=0 python tools/conv_timing.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralnetworklibrary_amd import ops  # noqa: E402
+from neuralnetworklibrary_amd._lib import check, lib, ptr, stream  # noqa: E402
+
+SHAPES = [('l1 bs64', 64, 64, 56, 64, 3, 1, 1), ('l3 bs64', 64, 256, 14, 256, 3, 1, 1), ('l1 bs8', 8, 64, 56, 64, 3, 1, 1),
+          ('l2 bs8', 8, 128, 28, 128, 3, 1, 1), ('l3 bs8', 8, 256, 14, 256, 3, 1, 1), ('l4 bs8', 8, 512, 7, 512, 3, 1, 1),
+          ('1x1 bs8', 8, 64, 56, 128, 1, 2, 0)]
+dev = 'cuda'
+cnt = ops._tile_counters(torch.device(dev))
+stamps = cnt[32768:].view(torch.int64).view(-1, 4)
+print('%-9s %6s | %8s %8s | %8s %8s %8s | %8s %8s' % ('shape', 'wgs', 'skew50', 'skewmax', 'prolog', 'loop', 'epilog', 'span', 'event'))
+for name, N, C, H, K, R, stride, pad in SHAPES:
+    g = ops._geom(N, H, H, C, K, R, R, stride, pad)
+    x = torch.randn(N, H, H, C, device=dev); w = torch.randn(K, R, R, C, device=dev) * 0.05
+    y = torch.empty(N, g.P, g.Q, K, device=dev)
+    fn = lambda: check(lib.nnl_conv2d_fwd(ptr(x), ptr(w), None, ptr(y), g, 0, None, 0, ptr(cnt), None, None, None, stream()))
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    stamps.zero_()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = stamps.cpu().numpy().astype(np.float64)
+    t = t[t[:, 0] > 0] / 100.0                                   # us (100 MHz counter)
+    t0 = t[:, 0].min()
+    print('%-9s %6d | %8.2f %8.2f | %8.2f %8.2f %8.2f | %8.2f %8.2f' % (
+        name, len(t), np.median(t[:, 0] - t0), (t[:, 0] - t0).max(), np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2] - t[:, 1]),
+        np.median(t[:, 3] - t[:, 2]), t[:, 3].max() - t0, a.elapsed_time(b) * 1e3))
