@@ -549,6 +549,7 @@ int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* 
     q.OH = 1; q.OW = 1; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
     q.M = M; q.Nc = N; q.b_row_stride = K; q.relu = relu; q.ntaps = 1;
     q.tap_dh[0] = 0; q.tap_dw[0] = 0; q.tap_aoff[0] = 0; q.tap_woff[0] = 0;
+    q.tap_affine = 1; q.tap_R = 1; q.tap_S = 1; q.tap_dstep = 1;
     return dispatch_taps(q, s);
   }
   return dispatch_rowk<IGEMM_MODE_FWD>(p, s);
@@ -566,6 +567,7 @@ int nnl_internal_gemm_nt_splitk(const float* a, const float* b, float* y_slabs, 
   q.OH = 1; q.OW = 1; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
   q.M = M; q.Nc = N; q.b_row_stride = K; q.relu = 0; q.ntaps = 1;
   q.tap_dh[0] = 0; q.tap_dw[0] = 0; q.tap_aoff[0] = 0; q.tap_woff[0] = 0;
+  q.tap_affine = 1; q.tap_R = 1; q.tap_S = 1; q.tap_dstep = 1;
   q.ksplit = splits; q.slab_stride = (long)M * N;
   return launch_taps<64, 64, 32>(q, s);
 }
@@ -672,6 +674,7 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
         q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
         q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
       }
+    q.tap_affine = NNL_ENV_INT("NNL_IGEMM_AFFINE", 1); q.tap_R = g->R; q.tap_S = g->S; q.tap_dh0 = 0; q.tap_dw0 = 0; q.tap_dstep = 1;
     q.bn_part = (bn_partials && bn_pivot && bn_rows) ? bn_partials : nullptr; q.bn_pivot = bn_pivot;
     return dispatch_taps(q, s, workspace, workspace_bytes, tile_counters, bn_rows);
   }
@@ -707,6 +710,7 @@ extern "C" int nnl_conv2d_fwd_add_up2(const float* x, const float* w, const floa
       q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
       q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
     }
+  q.tap_affine = NNL_ENV_INT("NNL_IGEMM_AFFINE", 1); q.tap_R = g->R; q.tap_S = g->S; q.tap_dh0 = 0; q.tap_dw0 = 0; q.tap_dstep = 1;
   return dispatch_taps(q, s);            // no workspace: the plain grid (the split-tile fix-up path reads a same-shape addend only)
 }
 
@@ -816,6 +820,9 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
       c.out_stride = st2; c.oh0 = cls[i].ph; c.ow0 = cls[i].pw;
       fill(c, cls[i], 0);
       c.ntaps = cls[i].nt;
+      if (st2 == 1 && cls[i].nt == g->R * g->S) {          // the full raster, r-major: (dh, dw) = (pad - r, pad - s), woff = t*K
+        c.tap_affine = NNL_ENV_INT("NNL_IGEMM_AFFINE", 1); c.tap_R = g->R; c.tap_S = g->S; c.tap_dh0 = g->pad; c.tap_dw0 = g->pad; c.tap_dstep = -1;
+      }
       int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes, tile_counters);
       if (st) return st;
     }

@@ -78,6 +78,11 @@ struct IgemmTapsParams {
   // the long tiles start first and the short ones fill the tail of the launch (M, P, Q are per class and equal for all).
   int ncls, cls_tiles;
   int cls_tap0[4], cls_ntaps[4], cls_oh0[4], cls_ow0[4];
+  // AFFINE taps (tap_affine != 0; dense forward / stride-1 dgrad / linear): tap t = r*tap_S + s of a full R x S raster has
+  // (dh, dw) = (tap_dh0 + r*tap_dstep, tap_dw0 + s*tap_dstep), aoff = (dh*W + dw)*C and woff = t*C — everything below is computed
+  // from these five scalars and the tables are never read.  (The table walk of the prologue was two dependent global byte loads
+  // per tap and row: 4.5 us per workgroup, tools/conv_timing.py.)
+  int tap_affine, tap_R, tap_S, tap_dh0, tap_dw0, tap_dstep;
   int tap_aoff[IGEMM_MAX_TAPS];        // (dh*W + dw)*C, elements (may be negative)
   int tap_woff[IGEMM_MAX_TAPS];        // offset of the tap's C weights inside a B row, elements
   signed char tap_dh[IGEMM_MAX_TAPS], tap_dw[IGEMM_MAX_TAPS];
@@ -194,11 +199,20 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
     const int h0 = pp * p.in_stride + p.ih0, w0 = qq * p.in_stride + p.iw0;
     a_off[i] = (((n * p.H + h0) * p.W + w0) * p.C + schunk(i) * 4) * 4;
     unsigned long long mask = 0;
-    if (valid)
-      for (int t = 0; t < ntaps; ++t) {
-        const int h = h0 + p.tap_dh[tap0 + t], w = w0 + p.tap_dw[tap0 + t];
-        if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) mask |= 1ull << t;
+    if (valid) {
+      if (p.tap_affine) {                           // R + S range tests, no table: row r is valid for every column bit of `cols`
+        unsigned cols = 0;
+        for (int ss = 0; ss < p.tap_S; ++ss)
+          if ((unsigned)(w0 + p.tap_dw0 + ss * p.tap_dstep) < (unsigned)p.W) cols |= 1u << ss;
+        for (int r = 0; r < p.tap_R; ++r)
+          if ((unsigned)(h0 + p.tap_dh0 + r * p.tap_dstep) < (unsigned)p.H) mask |= (unsigned long long)cols << (r * p.tap_S);
+      } else {
+        for (int t = 0; t < ntaps; ++t) {
+          const int h = h0 + p.tap_dh[tap0 + t], w = w0 + p.tap_dw[tap0 + t];
+          if ((unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W) mask |= 1ull << t;
+        }
       }
+    }
     a_mask[i] = mask;
   }
   unsigned b_off[PB];
@@ -221,8 +235,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
   unsigned a_voff[PA];
   unsigned b_tap = 0;
   auto set_tap = [&](int t) {
-    const int a_tap = p.tap_aoff[tap0 + t] * 4;          // may be negative; the sum with a valid row's base is not
-    b_tap = (unsigned)p.tap_woff[tap0 + t] * 4u;
+    int a_tap;                                           // may be negative; the sum with a valid row's base is not
+    if (p.tap_affine) {                                  // wave-uniform scalar arithmetic, once per tap
+      const int r = t / p.tap_S, ss = t - r * p.tap_S;
+      a_tap = ((p.tap_dh0 + r * p.tap_dstep) * p.W + p.tap_dw0 + ss * p.tap_dstep) * p.C * 4;
+      b_tap = (unsigned)(t * p.C) * 4u;
+    } else {
+      a_tap = p.tap_aoff[tap0 + t] * 4;
+      b_tap = (unsigned)p.tap_woff[tap0 + t] * 4u;
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) a_voff[i] = ((a_mask[i] >> t) & 1ull) ? (unsigned)(a_off[i] + a_tap) : 0xFFFFFFFFu;
   };

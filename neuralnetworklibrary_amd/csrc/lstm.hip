@@ -126,6 +126,7 @@ IgemmTapsParams step_params(const float* a, const float* b, float* slabs, int M,
   q.OH = 1; q.OW = 1; q.out_stride = 1; q.oh0 = 0; q.ow0 = 0;
   q.M = M; q.Nc = Nc; q.b_row_stride = K; q.relu = 0; q.ntaps = 1;
   q.tap_dh[0] = 0; q.tap_dw[0] = 0; q.tap_aoff[0] = 0; q.tap_woff[0] = 0;
+  q.tap_affine = 1; q.tap_R = 1; q.tap_S = 1; q.tap_dstep = 1;
   q.ksplit = ks; q.slab_stride = slab_stride;
   return q;
 }

@@ -384,4 +384,8 @@ def test_g15_retinanet_10_step_loss_curve_every_step_within_1e3():
     print('rel |ref32-f64|', np.array2string(np.abs(r32 - r64) / np.abs(r64), precision=1))
     assert (rel32 <= 1e-3).all(), 'step losses off the reference fp32 curve: worst %.2e at step %d' % (rel32.max(), rel32.argmax())
     abs_sums = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()])
-    assert_close(abs_sums, g['after.abs_sums.f32'], 1e-3, 1e-6, 'parameter |.|-sums after the 10 steps vs the reference fp32 run')
+    a32, a64 = g['after.abs_sums.f32'], g['after.abs_sums.f64']
+    tol = 3 * np.abs(a32 - a64) + 1e-3 * np.abs(a64) + 1e-6          # as far from fp64 as the reference's own fp32 run (x3) + 1e-3
+    bad = np.nonzero(np.abs(abs_sums - a64) > tol)[0]
+    assert len(bad) == 0, '%d parameter |.|-sums outside 3x the reference fp32/fp64 gap + 1e-3: %s' % (
+        len(bad), [(str(g['param_names'][i]), abs_sums[i], a32[i], a64[i]) for i in bad[:5]])

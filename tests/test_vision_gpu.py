@@ -245,5 +245,12 @@ def test_g13b_resnet34_20_step_loss_curve_every_step_within_1e3():
     print('rel |ref32-f64|', np.array2string(np.abs(r32 - r64) / np.abs(r64), precision=1))
     assert (rel32 <= 1e-3).all(), 'step losses off the reference fp32 curve: worst %.2e at step %d' % (rel32.max(), rel32.argmax())
     abs_sums = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()])
-    a32 = g['after.abs_sums.f32']
-    assert_close(abs_sums, a32, 1e-3, 1e-6, 'parameter |.|-sums after the 20 steps vs the reference fp32 run')
+    a32, a64 = g['after.abs_sums.f32'], g['after.abs_sums.f64']
+    # parameter |.|-sums after the 20 steps: as far from the reference's fp64 run as its own fp32 run is (x3) + 1e-3 — the BatchNorm
+    # shifts start at 0 and hold 20 tiny steps of pure gradient (|.|-sum 0.014), so their fp32 noise floor (6e-3 of the gradient,
+    # DESIGN 4) shows directly: the reference's own fp32 / fp64 runs differ by up to 1e-3 on them; + 1e-6 absolute: the shifts of the body
+    # groups (lr 1e-7 / 1e-6) have |.|-sums of 1e-5 in total, i.e. 1e-7 per element after 20 steps — rounding of the update itself
+    tol = 3 * np.abs(a32 - a64) + 1e-3 * np.abs(a64) + 1e-6
+    bad = np.nonzero(np.abs(abs_sums - a64) > tol)[0]
+    assert len(bad) == 0, '%d parameter |.|-sums outside 3x the reference fp32/fp64 gap + 1e-3: %s' % (
+        len(bad), [(str(g['param_names'][i]), abs_sums[i], a32[i], a64[i]) for i in bad[:5]])
