@@ -6,6 +6,11 @@
 #include "igemm_taps.h"
 #include "igemm_wgrad.h"
 
+#ifdef NNL_TAPS_TIMING
+static void* g_wgrad_dbg = nullptr;
+extern "C" void* nnl_debug_wgrad_stamps(void) { return g_wgrad_dbg; }       // timing builds only
+#endif
+
 namespace {
 
 int check_geom(const nnl_conv_geom_t* g, const char* who) {
@@ -105,7 +110,7 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   if (e_bal == 0 || Nc % 4 != 0) return best;
   const long gm = nnl_cdiv(M, bm), gn = nnl_cdiv(Nc, 64), T = gm * gn;
   const int e_bk = NNL_ENV_INT("NNL_IGEMM_BK32", -1);
-  const int bk = (bm == 64 && (e_bk >= 0 ? e_bk : (T < 1200 || C >= 256)) && C % 32 == 0) ? 32 : 16;
+  const int bk = (bm == 64 && (e_bk >= 0 ? e_bk : (T < 1200 || C >= 256 || C == 64)) && C % 32 == 0) ? 32 : 16;
   const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
   const double c_it = (bk == 32 ? 0.60 : 0.30) * (bm / 64);            // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
   const double occ = bm == 128 ? 5 : (bk == 32 ? 4 : 6);               // resident workgroups per CU (LDS- / VGPR-limited)
@@ -277,7 +282,9 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
       const int e_bk = NNL_ENV_INT("NNL_IGEMM_BK32", -1);
       const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64) * (p.ncls > 1 ? p.ncls : 1);
-      const int bk32 = e_bk >= 0 ? e_bk : (blocks64 < 1200 || p.C >= 256);   // long k loops (C >= 256) gain from BK=32 on large grids too (RetinaNet heads)
+      // long k loops (C >= 256) gain from BK=32 on large grids too (RetinaNet heads); so does C = 64 since the prologue / per-tap clean-ups
+      // of round 3 (re-measured per layer at 64 images: l1 3x3 0.143 -> 0.138 ms; the C = 128 stage still prefers BK=16: 0.138 vs 0.147)
+      const int bk32 = e_bk >= 0 ? e_bk : (blocks64 < 1200 || p.C >= 256 || p.C == 64);
       if (bk32 && p.C % 32 == 0) return launch_taps<64, 64, 32>(p, s);
       return launch_taps<64, 64>(p, s);
     }
@@ -464,8 +471,15 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
     const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
     const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
     const int f_sp = NNL_ENV_INT("NNL_WGRAD_SPLITS", 0);                  // A/B hook: force the split count
-    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5 || f_sp > 0); ++sp) {   // unsplit is always a candidate
+    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5 || f_sp > 0 || NNL_ENV_INT("NNL_WGRAD_WGPCU10", 0) > 0); ++sp) {   // unsplit is always a candidate
       if (f_sp > 0 && sp != (f_sp < max_splits ? f_sp : max_splits)) continue;
+      const int f_wg = NNL_ENV_INT("NNL_WGRAD_WGPCU10", 0);                // A/B hook: workgroups per CU x 10 (e.g. 20 = two per CU)
+      if (f_wg > 0) {
+        long want = (long)(f_wg * 25.6 / tiles + 0.5);
+        if (want < 1) want = 1;
+        if (want > max_splits) want = max_splits;
+        if (sp != want) continue;
+      }
       const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32) * 32;
       const long rs = nnl_cdiv(Kp, k1);
       if (rs != sp) continue;                                             // same plan as a smaller sp
@@ -500,6 +514,9 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   q.H = H; q.W = W; q.C = C; q.P = P; q.Q = Q; q.R = R; q.S = S; q.stride = stride; q.pad = pad;
   q.Mc = Mc; q.Nc = Nc; q.Kp = (int)Kp;
   q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
+#ifdef NNL_TAPS_TIMING
+  { static void* dbg = nullptr; if (!dbg) (void)hipMalloc(&dbg, 3276 * 5 * 8); q.dbg_t = (unsigned long long*)dbg; g_wgrad_dbg = dbg; }
+#endif
   {
     // Tile order inside a split: ~128 consecutive tiles run together on one XCD (32 CUs x 4 workgroups) and walk the pixel
     // range in step; per pixel row they touch (distinct row tiles) x bm columns of dy and (distinct column tiles) x bn of x.

@@ -132,9 +132,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
 #ifdef NNL_TAPS_TIMING
   // debug builds only (tools/gpu/*timing*): four 100 MHz timestamps per workgroup (entry, loop start, loop end, exit) in the upper
   // half of the caller's tile-counter buffer — where does the fixed ~14 us per launch go?
-  unsigned long long* const dbg_t = (p.tile_counters != nullptr && blockIdx.x < 4096 && blockIdx.y == 0)
-                                        ? reinterpret_cast<unsigned long long*>(p.tile_counters + 32768) + (long)blockIdx.x * 4 : nullptr;
-  if (dbg_t && tid == 0) dbg_t[0] = wall_clock64();
+  unsigned long long* const dbg_t = (p.tile_counters != nullptr && blockIdx.x < 3276 && blockIdx.y == 0)
+                                        ? reinterpret_cast<unsigned long long*>(p.tile_counters + 32768) + (long)blockIdx.x * 5 : nullptr;
+  if (dbg_t && tid == 0) {
+    dbg_t[0] = wall_clock64();
+    // where it runs: HW_ID (reg 4: cu_id bits 11:8, sh 12, se 15:13) and XCC_ID (reg 20, bits 3:0)
+    dbg_t[4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
 #define NNL_TSTAMP(i) do { if (dbg_t && tid == 0) dbg_t[i] = wall_clock64(); } while (0)
 #else
 #define NNL_TSTAMP(i) do { } while (0)

@@ -9,6 +9,7 @@
 #include "igemm_taps.h"
 
 struct IgemmWgradParams {
+  unsigned long long* dbg_t;   // timing builds only (NNL_TAPS_TIMING): 5 x u64 per workgroup, see igemm_taps.h
   const float* a;      // dy [Kp][Mc]
   const float* b;      // x  [N][H][W][C]
   float* y;            // [Mc][Nc] or [splits][Mc][Nc]
@@ -34,6 +35,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
+#ifdef NNL_TAPS_TIMING
+  unsigned long long* const dbg_t = (p.dbg_t != nullptr && blockIdx.x < 3276) ? p.dbg_t + (long)blockIdx.x * 5 : nullptr;
+  if (dbg_t && tid == 0) {
+    dbg_t[0] = wall_clock64();
+    dbg_t[4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
   const int tiles = p.grid_m * p.grid_n;
   // XCD-aware order: the hardware deals workgroups round-robin over the 8 XCDs; the remap gives each XCD a CONTIGUOUS range of
   // (split, tile) pairs, so the tiles of one split — which all stream the same pixel range of dy and x — share one L2
@@ -180,6 +188,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
     load_tile();
     store_tile(0);
     __syncthreads();
+    NNL_TSTAMP(1);
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) advance();                // the last iteration re-fetches the last tile (uniform; keeps one loop body)
@@ -193,6 +202,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
     }
   }
 
+  NNL_TSTAMP(2);
   float* out = p.y + (long)split * p.Mc * p.Nc;
   const int row_h = lh * 4;
 #pragma unroll
@@ -207,4 +217,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
       }
     }
   }
+#ifdef NNL_TAPS_TIMING
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  NNL_TSTAMP(3);
+#endif
 }
