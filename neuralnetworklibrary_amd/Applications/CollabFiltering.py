@@ -90,6 +90,8 @@ class CollabFilterNet(nn.Module):
     """y = lo + (hi-lo)*sigmoid(<user_emb[u], item_emb[i]> + user_bias[u] + item_bias[i])
     (Applications/CollabFiltering.py:168-213).  One layer group."""
 
+    nnl_default_graphs = True        # launch-bound at notebook batch sizes: Learner replays the whole step as a hipGraph by default
+
     def __init__(self, n_user, n_item, emb_dim, output_range):
         super().__init__()
         self.output_range = output_range

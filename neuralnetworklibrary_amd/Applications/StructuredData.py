@@ -105,6 +105,8 @@ class StructuredDataNet(nn.Module):
     (StructuredData.py:979-1084).  Same constructor, sub-module names and layer groups as the reference.
     `inject_masks(row_masks [n_cat, bs], cont_mask [bs, n_cont])` pins the dropout masks (parity tests)."""
 
+    nnl_default_graphs = True        # launch-bound at notebook batch sizes: Learner replays the whole step as a hipGraph by default
+
     def __init__(self, target_type, n_cat, n_cont, category_labels, fc_layer_sizes,
                  emb_sizes='default', output_range=None, dropout_levels=None):
         super().__init__()
