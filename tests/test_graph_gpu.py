@@ -3,6 +3,7 @@ hyper-parameters read from device memory), including lr / momentum / betas sched
 import numpy as np
 import pytest
 import torch
+import torch.nn as nn
 
 from conftest import assert_close
 
@@ -24,8 +25,7 @@ def _train(make, batches, bs, optimizer, graphs, sched, wd, clip=None, **kw):
     net = make()
     learner = Learner('/tmp/nnl_graph_test', Data(batches, bs, 'cont'), net, optimizer=optimizer)
     learner.init_optimizer(wd=wd, clip=clip)
-    if graphs:
-        learner.use_graphs(True, warmup=2)
+    learner.use_graphs(bool(graphs), warmup=2)        # (collab / tabular nets replay by default: the eager leg switches it off)
     learner.model.train()
     losses = []
     for i, lr in enumerate(sched):
@@ -206,3 +206,31 @@ def test_keyed_dropout_keeps_the_step_eager():
         assert len(set(losses)) > 3, losses
     finally:
         nnl_dist.drop_ctx.enabled = False
+
+
+def test_launch_bound_heads_replay_by_default(monkeypatch):
+    """CollabFilterNet / StructuredDataNet are marked `nnl_default_graphs`: a Learner on the GPU replays their whole step as a
+    hipGraph without the notebook asking for it (after the eager warm-up steps), `use_graphs(False)` and NNL_DEFAULT_GRAPHS=0
+    keep the per-launch path, and other models are unaffected."""
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterNet
+    from neuralnetworklibrary_amd.General.Core import make_model_basic, set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    g = torch.Generator().manual_seed(3)
+    batch = (torch.stack([torch.randint(0, 50, (64,), generator=g), torch.randint(0, 70, (64,), generator=g)], 1).to(DEV),
+             torch.randint(1, 6, (64,), generator=g).float().to(DEV))
+    learner = Learner('/tmp/nnl_graph_test', Data([batch], 64, 'cont'), CollabFilterNet(50, 70, 12, [0.8, 5.2]), optimizer='Adam')
+    assert learner._graph_warmup is not None
+    learner.init_optimizer(wd=1e-4)
+    learner.model.train()
+    for _ in range(5):
+        learner.train1minibatch(batch[0], batch[1], 1e-2)
+    assert sum(gs.graph is not None for gs in learner._graphs.values()) == 1
+    learner.use_graphs(False)
+    assert learner._graph_warmup is None
+    monkeypatch.setenv('NNL_DEFAULT_GRAPHS', '0')
+    assert Learner('/tmp/nnl_graph_test', Data([batch], 64, 'cont'), CollabFilterNet(50, 70, 12, [0.8, 5.2]))._graph_warmup is None
+    monkeypatch.delenv('NNL_DEFAULT_GRAPHS')
+    plain = make_model_basic(nn.Sequential(nn.Linear(4, 1), nn.Flatten(0)))
+    assert Learner('/tmp/nnl_graph_test', Data([batch], 64, 'cont'), plain)._graph_warmup is None
