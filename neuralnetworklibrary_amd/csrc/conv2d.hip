@@ -450,7 +450,7 @@ int colsum_chunks(long rows) {
   return (int)n;
 }
 
-struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split; };
+struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split, kg; };
 
 // Tile AND split count are searched together for the shortest predicted launch: all workgroups are resident at once
 // (occupancy 4-5), so a launch lasts ceil(blocks/256) x (pixels per split) x (time per workgroup-pixel of the tile); rounding
@@ -498,6 +498,24 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
     pl.grid_m = (int)nnl_cdiv(Mc, pl.bm); pl.grid_n = (int)nnl_cdiv(Nc, pl.bn);
     pl.splits = 1; pl.k_per_split = (int)(nnl_cdiv(Kp, 32) * 32);
   }
+  // Merge KG neighbouring splits into ONE workgroup of KG wave groups (igemm_wgrad.h): the same waves per CU, the partial sums of
+  // the KG pixel ranges meet in LDS, and only every KG-th slab is written / re-read (round 2 measured 1.97x the algorithmic HBM
+  // bytes per conv launch, almost all of it wgrad slabs).  Instantiated for the 128x128 (BK 16) and 64x64 (BK 32) tiles; the
+  // planner takes it only where it measured as a win (tools/bench_conv.py --ab NNL_WGRAD_KG=1,2,4 at 64 images): the 128x128 tile
+  // with >= 16 splits (28 x 28 / 14 x 14 stages: 0.139 -> 0.136 ms and 66 -> 17 MB of slabs per launch).  With few splits the merge
+  // unbalances the grid (7 x 7 stage, 7 splits: 0.142 -> 0.187 ms) and the 64x64 tile loses 1-3 %.
+  pl.kg = 1;
+  const int e_kg = NNL_ENV_INT("NNL_WGRAD_KG", -1);                       // A/B hook: 1 = off, 2 / 4 = force (when legal)
+  const bool kg_tile = (pl.bm == 128 && pl.bn == 128) || (pl.bm == 64 && pl.bn == 64);
+  if (kg_tile && e_kg != 1 && pl.splits >= 2) {
+    int kg = (pl.bm == 128 && pl.splits >= 16) ? 4 : 1;
+    if (e_kg == 2 || e_kg == 4) kg = pl.splits >= e_kg ? e_kg : 1;
+    if (kg > 1) {
+      const long sp = nnl_cdiv(pl.splits, kg);
+      const long k1 = nnl_cdiv(nnl_cdiv(Kp, sp), 32L * kg) * 32L * kg;    // each group's share stays a multiple of 32 pixels
+      pl.kg = kg; pl.k_per_split = (int)k1; pl.splits = (int)nnl_cdiv(Kp, k1);
+    }
+  }
   return pl;
 }
 
@@ -530,21 +548,41 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
   const int bk32 = NNL_ENV_INT("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
   const int pipe = NNL_ENV_INT("NNL_WGRAD_PIPE", 1);                 // A/B hook: 1 = software-pipelined fragment reads
+  // staging LDS: 2 buffers x BK x (BM + BN) floats per wave group (dynamic: above 64 KB the kernel needs the attribute once)
+  auto lds_bytes = [](int bm, int bn, int bk, int kg) { return (size_t)kg * 2 * bk * (bm + bn) * sizeof(float); };
+#define NNL_WGRAD_LAUNCH(BM_, BN_, BK_, PIPE_, KG_)                                                                              \
+  do {                                                                                                                           \
+    const size_t lb = lds_bytes(BM_, BN_, BK_, KG_);                                                                             \
+    if (lb > 64 * 1024) {                                                                                                        \
+      static bool attr_set = false;                                                                                              \
+      if (!attr_set) {                                                                                                           \
+        NNL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, PIPE_, KG_>),  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));                                 \
+        attr_set = true;                                                                                                         \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, PIPE_, KG_>), grid, dim3(256 * KG_), lb, s, q);                  \
+  } while (0)
   if (pl.bm == 128 && pl.bn == 128) {
-    if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2, true>), grid, block, 0, s, q);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<128, 128, 16, 2, 2>), grid, block, 0, s, q);   // BK=32 measured -7 % here
+    if (pl.kg == 4) NNL_WGRAD_LAUNCH(128, 128, 16, true, 4);
+    else if (pl.kg == 2) NNL_WGRAD_LAUNCH(128, 128, 16, true, 2);
+    else if (pipe) NNL_WGRAD_LAUNCH(128, 128, 16, true, 1);
+    else NNL_WGRAD_LAUNCH(128, 128, 16, false, 1);                     // BK=32 measured -7 % here
   } else if (pl.bm == 128) {
-    hipLaunchKernelGGL((igemm_wgrad_kernel<128, 64, 16, 2, 2>), grid, block, 0, s, q);
+    NNL_WGRAD_LAUNCH(128, 64, 16, false, 1);
   } else if (pl.bn == 128) {
-    hipLaunchKernelGGL((igemm_wgrad_kernel<64, 128, 16, 2, 2, true>), grid, block, 0, s, q);
+    NNL_WGRAD_LAUNCH(64, 128, 16, true, 1);
   } else {
     if (bk32 && pl.k_per_split % 32 == 0) {
-      if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2, true>), grid, block, 0, s, q);
-      else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 32, 2, 2>), grid, block, 0, s, q);
+      if (pl.kg == 4) NNL_WGRAD_LAUNCH(64, 64, 32, true, 4);
+      else if (pl.kg == 2) NNL_WGRAD_LAUNCH(64, 64, 32, true, 2);
+      else if (pipe) NNL_WGRAD_LAUNCH(64, 64, 32, true, 1);
+      else NNL_WGRAD_LAUNCH(64, 64, 32, false, 1);
     }
-    else if (pipe) hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2, true>), grid, block, 0, s, q);
-    else hipLaunchKernelGGL((igemm_wgrad_kernel<64, 64, 16, 2, 2>), grid, block, 0, s, q);
+    else if (pipe) NNL_WGRAD_LAUNCH(64, 64, 16, true, 1);
+    else NNL_WGRAD_LAUNCH(64, 64, 16, false, 1);
   }
+#undef NNL_WGRAD_LAUNCH
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

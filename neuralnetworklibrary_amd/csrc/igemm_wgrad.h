@@ -21,9 +21,14 @@ struct IgemmWgradParams {
   int n_fast;          // tile order inside a split: 1 = column tiles fastest (neighbours share the dy columns), 0 = row tiles fastest
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgrad_kernel(const IgemmWgradParams p) {
-  static_assert(WGM * WGN == 4, "4 waves per block");
+// KG > 1 (round 3): a workgroup is KG GROUPS of 4 waves (256*KG threads); group g reduces the g-th quarter / half of the split's
+// pixel range into its own accumulators with its own LDS staging buffers, and the groups' accumulators are added through LDS in
+// group order (deterministic) before group 0 writes ONE slab.  Same waves per CU as KG co-resident 256-thread workgroups, but KG
+// times fewer split-K slabs written to and re-read from HBM (the 128x128 tile at KG = 4: 66 MB -> 17 MB per launch).
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int KG = 1>
+__global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 : 4)) void igemm_wgrad_kernel(const IgemmWgradParams p) {
+  static_assert(WGM * WGN == 4, "4 waves per group");
+  static_assert(KG == 1 || (size_t)KG * 2 * BK * (BM + BN) >= (size_t)BM * BN, "the staging LDS must hold one accumulator tile for the group reduction");
   constexpr int CA = BM / 4, CB = BN / 4;
   constexpr int RA = 256 / CA, RB = 256 / CB;
   constexpr int PA = BK / RA, PB = BK / RB;
@@ -31,13 +36,16 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
 
-  __shared__ __attribute__((aligned(16))) float lds[2][BK * (BM + BN)];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // dynamic LDS (KG * 2 * BK * (BM + BN) floats: 128 KB for the 128x128 tile at KG = 4, above the 64 KB static limit)
+  extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
+  typedef float StageBuf[BK * (BM + BN)];
+  const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;      // wave-uniform group index
+  StageBuf* lds = reinterpret_cast<StageBuf*>(lds_dyn) + kg * 2;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
 #ifdef NNL_TAPS_TIMING
-  unsigned long long* const dbg_t = (p.dbg_t != nullptr && blockIdx.x < 3276) ? p.dbg_t + (long)blockIdx.x * 5 : nullptr;
-  if (dbg_t && tid == 0) {
+  unsigned long long* const dbg_t = (p.dbg_t != nullptr && blockIdx.x < 3276 && threadIdx.x < 256) ? p.dbg_t + (long)blockIdx.x * 5 : nullptr;
+  if (dbg_t && threadIdx.x == 0) {
     dbg_t[0] = wall_clock64();
     dbg_t[4] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
   }
@@ -51,8 +59,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   const int tile_n = p.n_fast ? t_id % p.grid_n : t_id / p.grid_m;
   const int tile_m = p.n_fast ? t_id / p.grid_n : t_id - tile_n * p.grid_m;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int k_begin = split * p.k_per_split;
-  const int k_end = min(k_begin + p.k_per_split, p.Kp);
+  int k_begin = split * p.k_per_split;
+  int k_end = min(k_begin + p.k_per_split, p.Kp);
+  int nk = (k_end - k_begin + BK - 1) / BK;
+  if constexpr (KG > 1) {
+    // every group runs the SAME number of k tiles (the barriers inside the loop are workgroup-wide); a group whose range is short or
+    // empty fetches zeros for the rest (the loads are predicated on k < k_end)
+    const int sub = ((p.k_per_split / KG + BK - 1) / BK) * BK;
+    nk = sub / BK;
+    k_begin = min(k_begin + kg * sub, k_end);
+    k_end = min(k_begin + sub, k_end);
+  }
 
   const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
@@ -183,7 +200,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
     }
   };
 
-  const int nk = (k_end - k_begin + BK - 1) / BK;
   if (nk > 0) {
     load_tile();
     store_tile(0);
@@ -203,6 +219,31 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_wgr
   }
 
   NNL_TSTAMP(2);
+  if constexpr (KG > 1) {
+    // acc(group 0) += acc(group 1) += ... in group order, through the staging LDS (free now: the k loop ended with a barrier)
+    float* scratch = lds_dyn;
+    for (int g = 1; g < KG; ++g) {
+      if (kg == g) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) scratch[((i * TN + j) * 16 + e) * 256 + tid] = acc[i][j][e];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += scratch[((i * TN + j) * 16 + e) * 256 + tid];
+      }
+      __syncthreads();
+    }
+    if (kg != 0) return;
+  }
   float* out = p.y + (long)split * p.Mc * p.Nc;
   const int row_h = lh * 4;
 #pragma unroll
