@@ -305,7 +305,7 @@ def committed_traffic(bs, sz, world):
     """HBM-side bytes per launch of the dominant kernel family: NOT measured by this run — it comes from separate
     `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this same command (tools/pmc_traffic.py; gfx950 corrections applied),
     committed under profiles/.  Reported only for the configuration those passes profiled."""
-    for name in ('r2_traffic.json', 'r1_traffic.json'):
+    for name in ('r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
         try:
             with open(os.path.join(ROOT, 'profiles', name)) as f:
                 t = json.load(f)
