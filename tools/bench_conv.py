@@ -25,6 +25,24 @@ LAYERS = [  # (name, C, H, K, R, stride, pad, count in ResNet-34)
 ]
 
 
+# RetinaNet R50-FPN at 512x512 (BASELINE configs[4], bs 16): (name, C, H, K, R, stride, pad, launches per step and direction)
+LAYERS_R50 = [
+    ('s1_1x1_64_64', 64, 128, 64, 1, 1, 0, 1), ('s1_1x1_256_64', 256, 128, 64, 1, 1, 0, 2), ('s1_3x3_64', 64, 128, 64, 3, 1, 1, 3),
+    ('s1_1x1_64_256', 64, 128, 256, 1, 1, 0, 4),
+    ('s2_1x1_256_128', 256, 128, 128, 1, 1, 0, 1), ('s2_3x3s2_128', 128, 128, 128, 3, 2, 1, 1), ('s2_1x1_512_128', 512, 64, 128, 1, 1, 0, 3),
+    ('s2_3x3_128', 128, 64, 128, 3, 1, 1, 3), ('s2_1x1_128_512', 128, 64, 512, 1, 1, 0, 4), ('s2_ds_256_512', 256, 128, 512, 1, 2, 0, 1),
+    ('s3_1x1_512_256', 512, 64, 256, 1, 1, 0, 1), ('s3_3x3s2_256', 256, 64, 256, 3, 2, 1, 1), ('s3_1x1_1024_256', 1024, 32, 256, 1, 1, 0, 5),
+    ('s3_3x3_256', 256, 32, 256, 3, 1, 1, 5), ('s3_1x1_256_1024', 256, 32, 1024, 1, 1, 0, 6), ('s3_ds_512_1024', 512, 64, 1024, 1, 2, 0, 1),
+    ('s4_1x1_1024_512', 1024, 32, 512, 1, 1, 0, 1), ('s4_3x3s2_512', 512, 32, 512, 3, 2, 1, 1), ('s4_1x1_2048_512', 2048, 16, 512, 1, 1, 0, 2),
+    ('s4_3x3_512', 512, 16, 512, 3, 1, 1, 2), ('s4_1x1_512_2048', 512, 16, 2048, 1, 1, 0, 3), ('s4_ds_1024_2048', 1024, 32, 2048, 1, 2, 0, 1),
+    ('fpn_lat_2048', 2048, 16, 256, 1, 1, 0, 1), ('fpn_lat_1024', 1024, 32, 256, 1, 1, 0, 1), ('fpn_lat_512', 512, 64, 256, 1, 1, 0, 1),
+    ('fpn_3x3_64', 256, 64, 256, 3, 1, 1, 1), ('fpn_3x3_32', 256, 32, 256, 3, 1, 1, 1), ('fpn_3x3_16', 256, 16, 256, 3, 1, 1, 1),
+    ('fpn_p6', 2048, 16, 256, 3, 2, 1, 1),
+    ('head_64', 256, 64, 256, 3, 1, 1, 8), ('head_32', 256, 32, 256, 3, 1, 1, 8), ('head_16', 256, 16, 256, 3, 1, 1, 8),
+    ('head_8', 256, 8, 256, 3, 1, 1, 8), ('head_4', 256, 4, 256, 3, 1, 1, 8), ('out_clas_64', 256, 64, 180, 3, 1, 1, 1),
+]
+
+
 def timeit(fn, iters=10):
     for _ in range(3):
         fn()
@@ -76,8 +94,12 @@ def ab(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bs', type=int, default=64)
+    ap.add_argument('--net', default='r34', help="'r34' (ResNet-34 at 224, default) or 'r50' (RetinaNet R50-FPN at 512)")
     ap.add_argument('--ab', default=None, help='A/B in ONE process, interleaved: ENVVAR=v0,v1[,v2] (e.g. NNL_IGEMM_BK32=0,1)')
     args = ap.parse_args()
+    global LAYERS
+    if args.net == 'r50':
+        LAYERS = LAYERS_R50
     if args.ab:
         return ab(args)
     dev = 'cuda'
