@@ -331,6 +331,17 @@ int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const floa
                  const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, int64_t T, int64_t B,
                  int64_t H, void* workspace, size_t workspace_bytes, int32_t* err_flag, void* stream);
 
+/* nn.MSELoss(reduction='mean') — `loss_func_dict['cont']` (General/Learner.py:20), the loss of the collaborative-filtering and
+ * structured-data heads: *loss = mean((pred - target)^2) over n fp32 elements (one launch up to 65 536 samples, fixed-order sum);
+ * backward: dpred = *grad_out (device scalar, NULL = 1) * 2 (pred - target) / n.  Workspace only above 65 536 samples. */
+size_t nnl_mse_workspace_bytes(int64_t n);
+int nnl_mse_fwd(const float* pred, const float* target, float* loss, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
+int nnl_mse_bwd(const float* pred, const float* target, const float* grad_out, float* dpred, int64_t n, void* stream);
+/* FullyConnectedNet's 'sigmoidal' output activation (General/Layers.py:150-152): y = lo + (hi - lo) * sig, sig = sigmoid(x) (both
+ * written); backward: dx = dy * (hi - lo) * sig * (1 - sig). */
+int nnl_scaled_sigmoid_fwd(const float* x, float* y, float* sig, int64_t n, float lo, float hi, void* stream);
+int nnl_scaled_sigmoid_bwd(const float* dy, const float* sig, float* dx, int64_t n, float lo, float hi, void* stream);
+
 /* ---- K5b: embedding with per-vocabulary-row dropout mask, fused softmax + cross-entropy -----------------------
  * nnl_embedding_rowmask_*: EmbeddingDropout.forward, F.embedding(x, W * mask[V,1], pad) (Text.py:465-475):
  * out[i,:] = W[x[i],:] * rowmask[x[i]] (rowmask NULL = ones); backward zero-fills dW [V,D] and scatter-adds

@@ -56,6 +56,8 @@ class Linear(nn.Module):
     def forward(self, x):
         if self.drop:
             x = self.drop(x)
+        if self.bn and x.dim() == 2:
+            return _ops().linear_relu_bn(self.lin, self.bn, x)           # BatchNorm statistics from the GEMM epilogue
         x = _ops().linear(x, self.lin.weight, self.lin.bias, relu=True)
         if self.bn:
             x = _ops().bn_act(self.bn, x, relu=False)
@@ -145,5 +147,5 @@ class FullyConnectedNet(nn.Module):
             x = F.log_softmax(x, dim=1).exp()
         elif self.final_activ == 'sigmoidal':
             lo, hi = float(self.output_range[0]), float(self.output_range[1])
-            x = lo + (hi - lo) * x.sigmoid()
+            x = _ops().scaled_sigmoid(x, lo, hi) if (x.is_cuda and hi != lo) else lo + (hi - lo) * x.sigmoid()
         return x

@@ -32,7 +32,7 @@ from .Core import (ARR, bn_types, combine_models, correct_foldername, default_de
 from .LossesMetrics import AUC
 from .Optimizer import Optimizer, get_param_dict
 
-__all__ = ['Learner', 'end_metrics', 'SGD_Mom', 'Adam2', 'opt_dict', 'loss_func_dict', 'plot_confusion_matrix']
+__all__ = ['Learner', 'HipMSELoss', 'HipCrossEntropyLoss', 'end_metrics', 'SGD_Mom', 'Adam2', 'opt_dict', 'loss_func_dict', 'plot_confusion_matrix']
 
 # registries (General/Learner.py:16-21)
 end_metrics = {'auc': AUC}
@@ -53,7 +53,20 @@ class HipCrossEntropyLoss(nn.CrossEntropyLoss):
         return super().forward(input, target)
 
 
-loss_func_dict = {'cont': nn.MSELoss(), 'cat': HipCrossEntropyLoss(), 'single_label': HipCrossEntropyLoss(),
+class HipMSELoss(nn.MSELoss):
+    """nn.MSELoss() (the default loss of the 'cont' target type, reference General/Learner.py:20) on the HIP kernels of csrc/loss.hip
+    (one launch forward, one backward — the collaborative-filtering / structured-data steps are launch-bound) when prediction
+    and target are same-shape CUDA tensors, the target needs no gradient and the reduction is 'mean'; torch's otherwise."""
+
+    def forward(self, input, target):
+        if (self.reduction == 'mean' and input.is_cuda and target.is_cuda and input.shape == target.shape and input.numel() > 0
+                and not target.requires_grad and input.dtype == torch.float32):
+            from ..ops import mse_loss
+            return mse_loss(input, target)
+        return super().forward(input, target)
+
+
+loss_func_dict = {'cont': HipMSELoss(), 'cat': HipCrossEntropyLoss(), 'single_label': HipCrossEntropyLoss(),
                   'multi_label': nn.BCEWithLogitsLoss()}
 
 

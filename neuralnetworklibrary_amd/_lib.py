@@ -86,6 +86,11 @@ SIGNATURES = {
     'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p, sz, c_p]),
     'nnl_softmax_ce_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, c_p, c_p]),
     'nnl_softmax_ce_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p]),
+    'nnl_mse_workspace_bytes': (sz, [i64]),
+    'nnl_mse_fwd': (C.c_int, [c_p, c_p, c_p, i64, c_p, sz, c_p]),
+    'nnl_mse_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, c_p]),
+    'nnl_scaled_sigmoid_fwd': (C.c_int, [c_p, c_p, c_p, i64, C.c_float, C.c_float, c_p]),
+    'nnl_scaled_sigmoid_bwd': (C.c_int, [c_p, c_p, c_p, i64, C.c_float, C.c_float, c_p]),
     'nnl_seq_reg_workspace_bytes': (sz, [i64, i64]),
     'nnl_seq_reg_fwd': (C.c_int, [c_p, c_p, i64, i64, C.c_float, C.c_float, c_p, sz, c_p]),
     'nnl_seq_reg_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, C.c_float, C.c_float, c_p]),

@@ -133,10 +133,15 @@ extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float*
   NNL_CHECK_ARG(n >= 0 && n_user > 0 && n_item > 0 && D > 0 && D < (1 << 30), "embdotbias_bwd: bad sizes");
   NNL_CHECK_ARG(dU && dM && dbu && dbi, "embdotbias_bwd: null output");
   hipStream_t s = (hipStream_t)stream;
-  NNL_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * n_user * D, s));
-  NNL_CHECK_HIP(hipMemsetAsync(dM, 0, sizeof(float) * n_item * D, s));
-  NNL_CHECK_HIP(hipMemsetAsync(dbu, 0, sizeof(float) * n_user, s));
-  NNL_CHECK_HIP(hipMemsetAsync(dbi, 0, sizeof(float) * n_item, s));
+  if (dM == dU + n_user * D && dbu == dM + n_item * D && dbi == dbu + n_user) {
+    // the four gradients are one allocation ([dU | dM | dbu | dbi], as ops.py hands them over): one fill instead of four
+    NNL_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * ((n_user + n_item) * (D + 1)), s));
+  } else {
+    NNL_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * n_user * D, s));
+    NNL_CHECK_HIP(hipMemsetAsync(dM, 0, sizeof(float) * n_item * D, s));
+    NNL_CHECK_HIP(hipMemsetAsync(dbu, 0, sizeof(float) * n_user, s));
+    NNL_CHECK_HIP(hipMemsetAsync(dbi, 0, sizeof(float) * n_item, s));
+  }
   if (n == 0) return NNL_OK;
   NNL_CHECK_ARG(x && U && M && dy && (z || !has_range), "embdotbias_bwd: null pointer");
   NnlProfScope prof(NNL_PROF_EMBDOT, s, (double)n * (16 + 16.0 * D + 8 + 8));
@@ -151,18 +156,20 @@ extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float*
     nnl_det::SegSumParams q{};
     q.idx = x; q.idx_stride = 2; q.n = (int)n; q.scale_i = g; q.scale_i_stride = 0; q.skip_row = -1;
     q.srcrow = x; q.srcrow_stride = 2;
-    // dU[u] = sum g * M[item];  dM[item] = sum g * U[u]: the "column" of a launch is selected by offsetting idx / order
+    // dU[u] = sum g * M[item];  dM[item] = sum g * U[u];  dbu[u] = sum g;  dbi[item] = sum g — ONE launch, four parameter sets
+    // (the "column" of a set is selected by offsetting idx / order)
+    nnl_det::SegSumParams4 ps{};
     q.order = order; q.card = n_user; q.D = (int)D; q.dst = dU; q.src = M; q.ld = D; q.srcrow_col = 1; q.srcrow_card = n_item;
-    if ((st = nnl_det::segsum(q, 1, s))) return st;
+    ps.q[0] = q;
     nnl_det::SegSumParams r = q;
     r.idx = x + 1; r.order = order + n; r.card = n_item; r.dst = dM; r.src = U; r.srcrow = x; r.srcrow_col = 0; r.srcrow_card = n_user;
-    if ((st = nnl_det::segsum(r, 1, s))) return st;
-    // biases: dst[row] = sum g
+    ps.q[1] = r;
     nnl_det::SegSumParams b = q;
     b.D = 1; b.dst = dbu; b.src = g; b.ld = 1; b.srcrow = nullptr; b.srcrow_card = 0; b.scale_i = nullptr;
-    if ((st = nnl_det::segsum(b, 1, s))) return st;
+    ps.q[2] = b;
     b.idx = x + 1; b.order = order + n; b.card = n_item; b.dst = dbi;
-    return nnl_det::segsum(b, 1, s);
+    ps.q[3] = b;
+    return nnl_det::segsum4(ps, 4, s);
   }
   hipLaunchKernelGGL(embdotbias_bwd_kernel, dim3(grid_for(n)), dim3(kBlock), 0, s, x, U, M, z, dy, dU, dM,
                      dbu, dbi, n, n_user, n_item, (int)D, has_range, lo, hi);

@@ -56,8 +56,8 @@ struct SegSumParams {
   long skip_row;                                  // a row that receives no gradient (padding_idx), or -1
 };
 
-static __global__ __launch_bounds__(256) void segsum_kernel(SegSumParams p) {
-  const int c = blockIdx.y, lane = threadIdx.x & 63;
+static __device__ __forceinline__ void segsum_body(const SegSumParams& p, const int c) {
+  const int lane = threadIdx.x & 63;
   const int pos = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (pos >= p.n) return;
   const int* ord = p.order + (long)c * p.n;
@@ -102,6 +102,13 @@ static __global__ __launch_bounds__(256) void segsum_kernel(SegSumParams p) {
   }
 }
 
+static __global__ __launch_bounds__(256) void segsum_kernel(SegSumParams p) { segsum_body(p, blockIdx.y); }
+
+// up to four INDEPENDENT segment sums (own destination, source, row indirection, width) in one launch: blockIdx.y picks the set
+// (EmbeddingDotBias: dU, dM, dbu, dbi — four launches of a 64-sample step were four graph nodes of ~3 us each)
+struct SegSumParams4 { SegSumParams q[4]; };
+static __global__ __launch_bounds__(256) void segsum4_kernel(SegSumParams4 ps) { segsum_body(ps.q[blockIdx.y], 0); }
+
 static inline size_t order_bytes(long n, int ncols) { return (size_t)n * ncols * sizeof(int); }
 
 static inline int sort_rows(const int64_t* idx, long stride, long n, int ncols, int* order, hipStream_t s) {
@@ -112,6 +119,12 @@ static inline int sort_rows(const int64_t* idx, long stride, long n, int ncols, 
 
 static inline int segsum(const SegSumParams& p, int ncols, hipStream_t s) {
   hipLaunchKernelGGL(segsum_kernel, dim3((unsigned)nnl_cdiv(p.n, 4), ncols), dim3(256), 0, s, p);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+static inline int segsum4(const SegSumParams4& ps, int nsets, hipStream_t s) {
+  hipLaunchKernelGGL(segsum4_kernel, dim3((unsigned)nnl_cdiv(ps.q[0].n, 4), nsets), dim3(256), 0, s, ps);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

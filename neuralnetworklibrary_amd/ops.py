@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, require_cuda, stream
 
-__all__ = ['embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc', 'linear', 'bn_act', 'concat_pool2d', 'TabularPlan', 'tab_embed_concat', 'embedding_renorm_drop', 'retina_loss']
+__all__ = ['mse_loss', 'scaled_sigmoid', 'embdotbias', 'index_error_flag', 'raise_if_index_error', 'conv2d', 'to_nhwc', 'from_nhwc', 'linear', 'bn_act', 'concat_pool2d', 'TabularPlan', 'tab_embed_concat', 'embedding_renorm_drop', 'retina_loss']
 
 _ERR_FLAGS = {}
 
@@ -87,15 +87,72 @@ class _EmbDotBias(torch.autograd.Function):
         x, U, M, z = ctx.saved_tensors
         has_range, lo, hi = ctx.rng
         dy = _f32c(dy)
-        dU, dM = torch.empty_like(U), torch.empty_like(M)
-        dbu = torch.empty(U.shape[0], 1, dtype=torch.float32, device=U.device)
-        dbi = torch.empty(M.shape[0], 1, dtype=torch.float32, device=U.device)
+        nu, ni, D = U.shape[0], M.shape[0], U.shape[1]
+        flat = torch.empty((nu + ni) * (D + 1), dtype=torch.float32, device=U.device)       # [dU | dM | dbu | dbi]: one fill in C
+        dU, dM = flat[:nu * D].view(nu, D), flat[nu * D:(nu + ni) * D].view(ni, D)
+        dbu, dbi = flat[(nu + ni) * D:(nu + ni) * D + nu].view(nu, 1), flat[(nu + ni) * D + nu:].view(ni, 1)
         wsb = int(lib.nnl_embdotbias_bwd_workspace_bytes(x.shape[0]))          # sample-order (deterministic) scatter-add
         ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=U.device)
         check(lib.nnl_embdotbias_bwd(ptr(x), ptr(U), ptr(M), ptr(z), ptr(dy), ptr(dU), ptr(dM), ptr(dbu), ptr(dbi),
                                      x.shape[0], U.shape[0], M.shape[0], U.shape[1], int(has_range), lo, hi,
                                      ptr(ws), wsb, stream()))
         return None, dU, dM, dbu, dbi, None, None
+
+
+class _MSE(torch.autograd.Function):
+    """nn.MSELoss() (reference General/Learner.py:20, the 'cont' loss): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        require_cuda(pred, target)
+        p, t = _f32c(pred).reshape(-1), _f32c(target).reshape(-1)
+        n = p.numel()
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        wsb = int(lib.nnl_mse_workspace_bytes(n))
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=p.device) if wsb else None
+        check(lib.nnl_mse_fwd(ptr(p), ptr(t), ptr(loss), n, ptr(ws), wsb, stream()))
+        ctx.save_for_backward(p, t)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        p, t = ctx.saved_tensors
+        g = _f32c(dloss).reshape(1)
+        dp = torch.empty_like(p)
+        check(lib.nnl_mse_bwd(ptr(p), ptr(t), ptr(g), ptr(dp), p.numel(), stream()))
+        return dp.view(ctx.shape), None
+
+
+def mse_loss(pred, target):
+    "mean((pred - target)^2) as a 0-dim tensor; gradient with respect to `pred` only (targets are data)"
+    return _MSE.apply(pred, target)
+
+
+class _ScaledSigmoid(torch.autograd.Function):
+    """lo + (hi - lo) * sigmoid(x): FullyConnectedNet's 'sigmoidal' output activation (reference General/Layers.py:150-152)"""
+
+    @staticmethod
+    def forward(ctx, x, lo, hi):
+        require_cuda(x)
+        xc = _f32c(x)
+        y, sg = torch.empty_like(xc), torch.empty_like(xc)
+        check(lib.nnl_scaled_sigmoid_fwd(ptr(xc), ptr(y), ptr(sg), xc.numel(), float(lo), float(hi), stream()))
+        ctx.save_for_backward(sg)
+        ctx.rng = (float(lo), float(hi))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sg, = ctx.saved_tensors
+        dyc = _f32c(dy)
+        dx = torch.empty_like(sg)
+        check(lib.nnl_scaled_sigmoid_bwd(ptr(dyc), ptr(sg), ptr(dx), sg.numel(), ctx.rng[0], ctx.rng[1], stream()))
+        return dx, None, None
+
+
+def scaled_sigmoid(x, lo, hi):
+    return _ScaledSigmoid.apply(x, float(lo), float(hi))
 
 
 def embdotbias(x, U, M, bu, bi, output_range=None):
@@ -722,6 +779,25 @@ def conv_bn_act(conv, bn, x, residual=None, relu=True, conv_slot=None, bn_slot=N
         return bn_act(bn, conv(x, grad_slot=conv_slot, give_slot=conv_give), residual=residual, relu=relu, grad_slot=bn_slot, pivot_out=pivot)
     y, part = conv2d_with_bn_stats(x, conv.weight, None, conv.stride[0], conv.padding[0], pivot, conv_slot, conv_give)
     return bn_act(bn, y, residual=residual, relu=relu, grad_slot=bn_slot, ext_stats=(part, pivot), pivot_out=pivot)
+
+
+def linear_relu_bn(lin, bn, x):
+    """bn(relu(lin(x))) — the Linear block of FullyConnectedNet (reference General/Layers.py:37-41: Linear -> ReLU -> BatchNorm1d, BN
+    AFTER the ReLU).  In training mode the GEMM's epilogue reduces the batch statistics of relu(x W^T + b) as shifted sums (as
+    conv_bn_act does for convolutions), so the BatchNorm1d does not re-read the activation for them."""
+    fuse = (bn.training and bn.track_running_stats and bn.running_mean is not None and bn.momentum is not None
+            and getattr(bn, 'nnl_sync', None) is None and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled()
+            and os.environ.get('NNL_BN_EPI_STATS', '1') != '0')
+    pivot = getattr(bn, '_nnl_pivot', None) if fuse else None
+    if not fuse or pivot is None or pivot.device != x.device or pivot.numel() != bn.num_features:
+        y = linear(x, lin.weight, lin.bias, relu=True)
+        if not fuse or torch.cuda.is_current_stream_capturing():
+            return bn_act(bn, y, relu=False)
+        pivot = torch.empty(bn.num_features, dtype=torch.float32, device=x.device)
+        object.__setattr__(bn, '_nnl_pivot', pivot)                  # plain attribute: not a buffer, not in the state_dict
+        return bn_act(bn, y, relu=False, pivot_out=pivot)
+    y, part = _Conv2d.apply(x[:, :, None, None], lin.weight[:, :, None, None], lin.bias, 1, 0, 1, None, pivot, None)
+    return bn_act(bn, y.reshape(x.shape[0], lin.weight.shape[0]), relu=False, ext_stats=(part, pivot), pivot_out=pivot)
 
 
 def concat_pool2d(x):

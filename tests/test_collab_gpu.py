@@ -201,3 +201,23 @@ def test_embedding_gradients_are_bitwise_reproducible_and_in_sample_order():
     assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
     assert float(res[0][1].abs().sum()) == 0.0
     ops.raise_if_index_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 64, 1024, 70001])
+def test_hip_mse_loss_vs_torch(n):
+    """nn.MSELoss() of the 'cont' target type (reference General/Learner.py:20) on the HIP kernels: value and gradient against torch
+    in fp64, an upstream gradient other than 1, and bitwise reproducibility of the fixed-order sum."""
+    from neuralnetworklibrary_amd import ops
+    from neuralnetworklibrary_amd.General.Learner import loss_func_dict
+    g = torch.Generator().manual_seed(n)
+    p, t = torch.randn(n, generator=g) * 3, torch.randn(n, generator=g)
+    p64 = p.double().requires_grad_(True)
+    ref = ((p64 - t.double()) ** 2).mean()
+    (2.5 * ref).backward()
+    pd = p.to(DEV).requires_grad_(True)
+    out = loss_func_dict['cont'](pd, t.to(DEV))
+    (2.5 * out).backward()
+    assert_close(out.reshape(1), np.array([float(ref)]), 2e-6, 1e-7, 'value')
+    assert_close(pd.grad, p64.grad.float(), 1e-6, 1e-7 * float(p64.grad.abs().max()), 'd pred')
+    assert torch.equal(ops.mse_loss(pd.detach(), t.to(DEV)), ops.mse_loss(pd.detach(), t.to(DEV)))

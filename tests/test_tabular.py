@@ -160,3 +160,20 @@ def test_rossmann_shape_with_dropout_masks_vs_oracle():
     for (n, p), (_, q) in zip(prod.named_parameters(), orac.named_parameters()):
         assert_close(p.grad, q.grad, 1e-3, 1e-4 * max(q.grad.abs().max().item(), 1e-6), 'grad ' + n)
         assert_close(p, q, 1e-6, 1e-7, 'renormed ' + n)
+
+
+@pytest.mark.gpu
+def test_scaled_sigmoid_output_activation():
+    "FullyConnectedNet's 'sigmoidal' activation (reference General/Layers.py:150-152) as one kernel each way vs torch in fp64"
+    from neuralnetworklibrary_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1024, 1, generator=g) * 3
+    x64 = x.double().requires_grad_(True)
+    ref = 5.0 + (12.0 - 5.0) * x64.sigmoid()
+    dy = torch.randn(1024, 1, generator=g)
+    ref.backward(dy.double())
+    xd = x.to('cuda').requires_grad_(True)
+    out = ops.scaled_sigmoid(xd, 5.0, 12.0)
+    out.backward(dy.to('cuda'))
+    assert_close(out, ref.float(), 1e-6, 1e-6, 'y')
+    assert_close(xd.grad, x64.grad.float(), 2e-5, 1e-6, 'dx')
