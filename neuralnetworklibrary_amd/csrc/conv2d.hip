@@ -341,8 +341,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const long i = (long)blockIdx.x * 32 + col;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (i < n4)
-    for (int s = sl; s < splits; s += 8) acc += reinterpret_cast<const f32x4*>(part)[(long)s * n4 + i];
+  if (i < n4) {
+    // lane `sl` adds slabs sl, sl+8, ... IN THAT ORDER; four loads in flight per trip (the plain loop waited for each load)
+    int s = sl;
+    for (; s + 24 < splits; s += 32) {
+      const f32x4 v0 = reinterpret_cast<const f32x4*>(part)[(long)s * n4 + i], v1 = reinterpret_cast<const f32x4*>(part)[(long)(s + 8) * n4 + i];
+      const f32x4 v2 = reinterpret_cast<const f32x4*>(part)[(long)(s + 16) * n4 + i], v3 = reinterpret_cast<const f32x4*>(part)[(long)(s + 24) * n4 + i];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; s < splits; s += 8) acc += reinterpret_cast<const f32x4*>(part)[(long)s * n4 + i];
+  }
   red[sl][col] = acc;
   __syncthreads();
   if (sl == 0 && i < n4) {

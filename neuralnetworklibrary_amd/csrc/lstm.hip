@@ -48,6 +48,38 @@ __global__ void pad_copy_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
+// acc + p[0] + p[stride] + ... + p[(n-1)*stride], added IN SLAB ORDER (bitwise the same sum as the plain loop) but with up to 16
+// loads in flight: the plain loop compiled to load -> s_waitcnt vmcnt(0) -> add per slab, i.e. 14 serialized L2 round trips per
+// element — 7 of the 8 us of the BPTT cell kernel (round 3, found in the ISA)
+__device__ __forceinline__ float add_slabs(float acc, const float* __restrict__ p, int n, long stride) {
+  int s = 0;
+  for (; s + 16 <= n; s += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = p[(long)(s + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += v[j];
+  }
+  if (s + 8 <= n) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = p[(long)(s + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+    s += 8;
+  }
+  if (s + 4 <= n) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = p[(long)(s + j) * stride];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += v[j];
+    s += 4;
+  }
+  for (; s < n; ++s) acc += p[(long)s * stride];
+  return acc;
+}
+
 // dh = dy_t + sum_s dh_slab[s]; gates (activated), c_t, c_prev; dc in/out (dc_next -> dc_prev); dgates [B,Gp] (Gp >= 4H,
 // pad columns are never written and stay zero)
 __global__ void lstm_cell_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dh_slabs, int nslab,
@@ -60,7 +92,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ dy, const float* 
     const float* g = gates + (long)b * 4 * H;
     const float gi = g[u], gf = g[H + u], gg = g[2 * H + u], go = g[3 * H + u];
     float dh = dy ? dy[i] : 0.f;
-    for (int s = 0; s < nslab; ++s) dh += dh_slabs[s * slab_stride + i];
+    dh = add_slabs(dh, dh_slabs + i, nslab, slab_stride);
     const float tc = tanhf(c[i]);
     const float dcn = dc[i] + dh * go * (1.f - tc * tc);
     float* dg = dgates + (long)b * Gp;
@@ -74,9 +106,7 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ dy, const float* 
 
 __global__ void sum_slabs_kernel(const float* __restrict__ slabs, int nslab, long slab_stride, float* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int s = 0; s < nslab; ++s) v += slabs[s * slab_stride + i];
-    out[i] = v;
+    out[i] = add_slabs(0.f, slabs + i, nslab, slab_stride);
   }
 }
 
