@@ -496,16 +496,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
         const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = (idx4 & 15) * 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (m0 + rl < p.M) {
-          f32x4 part[8];
-          const int ns = nslices < 8 ? nslices : 8;
+          for (int sl0 = 0; sl0 < nslices; sl0 += 8) {
+            f32x4 part[8];
 #pragma unroll
-          for (int sl = 0; sl < 8; ++sl)
-            if (sl < ns) part[sl] = buf_load4_pol(rs, (unsigned)(((long)sl * p.slab_stride + (long)(m0 + rl) * Nlog + n0 + c4) * 4), kSc1);
+            for (int sl = 0; sl < 8; ++sl)
+              if (sl0 + sl < nslices) part[sl] = buf_load4_pol(rs, (unsigned)(((long)(sl0 + sl) * p.slab_stride + (long)(m0 + rl) * Nlog + n0 + c4) * 4), kSc1);
 #pragma unroll
-          for (int sl = 0; sl < 8; ++sl)
-            if (sl < ns) v += part[sl];
-          for (int sl = 8; sl < nslices; ++sl)
-            v += buf_load4_pol(rs, (unsigned)(((long)sl * p.slab_stride + (long)(m0 + rl) * Nlog + n0 + c4) * 4), kSc1);
+            for (int sl = 0; sl < 8; ++sl)
+              if (sl0 + sl < nslices) v += part[sl];
+          }
         }
         *reinterpret_cast<f32x4*>(tl + rl * LDT + c4) = v;
       }
@@ -584,16 +583,15 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       const int row = m0 + rl;
       if (row >= p.M || c4 >= p.Nc) continue;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      f32x4 part[8];
-      const int ns = nslices < 8 ? nslices : 8;
+      for (int sl0 = 0; sl0 < nslices; sl0 += 8) {     // eight slab loads in flight per trip, added in slice order (the loop that
+        f32x4 part[8];                                 // followed the first eight used to wait for every single load)
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl)
-        if (sl < ns) part[sl] = buf_load4_pol(rs, (unsigned)(((long)sl * sstride + (long)(row - row0) * p.Nc + c4) * 4), kSc1);
+        for (int sl = 0; sl < 8; ++sl)
+          if (sl0 + sl < nslices) part[sl] = buf_load4_pol(rs, (unsigned)(((long)(sl0 + sl) * sstride + (long)(row - row0) * p.Nc + c4) * 4), kSc1);
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl)
-        if (sl < ns) v += part[sl];
-      for (int sl = 8; sl < nslices; ++sl)
-        v += buf_load4_pol(rs, (unsigned)(((long)sl * sstride + (long)(row - row0) * p.Nc + c4) * 4), kSc1);
+        for (int sl = 0; sl < 8; ++sl)
+          if (sl0 + sl < nslices) v += part[sl];
+      }
       const long o = (long)row * p.Nc + c4;
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
       if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);

@@ -216,7 +216,20 @@ __global__ __launch_bounds__(kRegBlock) void seq_reg_partial_kernel(const float*
   for (long c = (long)blockIdx.x * kRegBlock + threadIdx.x; c < R; c += (long)gridDim.x * kRegBlock) {
     float prev = h[c];
     ar += prev * prev;
-    for (int t = 1; t < T; ++t) {
+    int t = 1;
+    for (; t + 8 <= T; t += 8) {                  // eight loads in flight (a load -> wait -> use loop is T serialized round trips)
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = h[(long)(t + j) * R + c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = v[j] - prev;
+        ar += v[j] * v[j];
+        tar += d * d;
+        prev = v[j];
+      }
+    }
+    for (; t < T; ++t) {
       const float v = h[(long)t * R + c];
       const float d = v - prev;
       ar += v * v;
