@@ -123,6 +123,8 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   const double plain = wave_iters(T, I) * c_it;
   best.t_us = plain;
   double best_t = plain * (e_bal == 2 ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
+  const int plan_extra = NNL_ENV_INT("NNL_IGEMM_PLAN_EXTRA", 2);                       // k iterations' worth of fix-up cost per sliced workgroup
+  const double plan_bw = NNL_ENV_INT("NNL_IGEMM_PLAN_BW", 16000) * 1.0e3;                  // slab traffic bandwidth, bytes per us
   const int f_ks = NNL_ENV_INT("NNL_IGEMM_PLAN_KS", 0), f_S = NNL_ENV_INT("NNL_IGEMM_PLAN_S", 0);   // A/B hooks: force the plan's k slicing
   if (f_ks > 0 || f_S > 0) best_t = 1e300;
   for (int ks = 1; ks <= 4; ks *= 2) {
@@ -140,11 +142,11 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
       if (f_S > 0 && tail > 0 && S != f_S) continue;
       const long it_tail = nnl_cdiv(I, S);
       const long tail_blocks = tail * S;
-      double t = (wave_iters(n_main * ks, it_main) + wave_iters(tail_blocks, it_tail + (S > 1 ? 2 : 0))) * c_it;
+      double t = (wave_iters(n_main * ks, it_main) + wave_iters(tail_blocks, it_tail + (S > 1 ? plan_extra : 0))) * c_it;
       const long row0 = (n_main / gn) * bm < M ? (n_main / gn) * bm : M;
       const double main_b = ks > 1 ? (2.0 * ks + 1) * row0 * Nc * 4 : 0;
       const double tail_b = S > 1 ? (2.0 * S + 1) * (M - row0) * Nc * 4 : 0;
-      t += (main_b + tail_b) / 4.0e6 + (ks > 1 ? 1 : 0) + (S > 1 && tail ? 1 : 0);      // reduce traffic at ~4 TB/s + launch gap
+      t += (main_b + tail_b) / plan_bw + (ks > 1 ? 1 : 0) + (S > 1 && tail ? 1 : 0);      // slab traffic (write + re-read) + fix-up latency
       if (t < best_t) {
         best_t = t;
         best.t_us = t;
