@@ -28,6 +28,18 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef NNL_TAPS_TIMING
+// timing builds only (tools/build_timing_lib.sh): per timestep, workgroups 0 / 77 / 153 / 229 record six 100 MHz timestamps
+// (step start, k loop done, h published, arrived, tape stores issued, barrier passed) — tools/lstm_timing.py reads them back
+__device__ unsigned long long g_lstm_stamps[4 * 128 * 6];
+extern "C" int nnl_debug_lstm_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_lstm_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#define NNL_LSTAMP(i) do { if (dbg_slot >= 0 && threadIdx.x == 0 && t < 128) g_lstm_stamps[(dbg_slot * 128 + t) * 6 + (i)] = wall_clock64(); } while (0)
+#else
+#define NNL_LSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -199,7 +211,11 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
   const int rot = blockIdx.x;                             // any two workgroups of an XCD start at different chunks, however the XCDs are assigned
   const int ln = lane < B ? lane : 0, wcol = lane < 4 * NG ? lane : 4 * NG - 1;
   const long BH = (long)B * H, BG = (long)B * 4 * H, slot = (long)p.Kp * kLanes;
+#ifdef NNL_TAPS_TIMING
+  const int dbg_slot = blockIdx.x == 0 ? 0 : ((int)blockIdx.x == p.NWG / 3 ? 1 : ((int)blockIdx.x == 2 * p.NWG / 3 ? 2 : ((int)blockIdx.x == p.NWG - 1 ? 3 : -1)));
+#endif
   for (int t = 0; t < p.T; ++t) {
+    NNL_LSTAMP(0);
     // this step's input projections: issued before the k loop, consumed after it
     float gxv[2][4];
 #pragma unroll
@@ -215,6 +231,7 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
 #pragma unroll
       for (int v = 0; v < 4; ++v) red[((long)wave * ncol + 4 * g + v) * kLanes + lane] = acc[g][v];
     __syncthreads();
+    NNL_LSTAMP(1);
     float* hs = p.xT + (t + 1) * slot;
     float hv[2], gact[2][4];
 #pragma unroll
@@ -238,7 +255,9 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
       if (pok[q]) __hip_atomic_store(hs + (long)(u0 + pu[q]) * kLanes + pb[q], hv[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const bool more = t + 1 < p.T;
+    NNL_LSTAMP(2);
     if (more) grid_arrive(p.arrive, t);
+    NNL_LSTAMP(3);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (pok[q]) {
@@ -250,7 +269,9 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
         for (int g = 0; g < 4; ++g) gt[(long)g * H] = gact[q][g];
       }
     }
+    NNL_LSTAMP(4);
     if (more && !(p.dbg & 2) && !grid_wait(p.arrive, t, p.NWG, p.err, &s_flag)) return;
+    NNL_LSTAMP(5);
   }
 }
 
