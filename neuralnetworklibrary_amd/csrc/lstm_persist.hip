@@ -61,6 +61,7 @@ struct PersistFwd {
   int* err;
   int T, B, H, Kp, U, NWG;
   int dbg;              // timing experiments only (NNL_LSTM_DBG): 1 = no k loop, 2 = no grid wait
+  int single;           // 1: the single-chunk k loop where it is instantiated (NNL_LSTM_SINGLE, default 1)
 };
 
 struct PersistBwd {
@@ -140,6 +141,39 @@ __device__ __forceinline__ void panel(const float* __restrict__ xs, const float*
   }
 }
 
+// Single-chunk variant (round 3): ALL of the wave's k rows are requested at once — PDS groups of 4 rows, one dword per lane and row
+// (PDS = 36 at H = 1150: 144 loads, 144 VGPRs; the kernel runs one 512-thread workgroup per CU, i.e. 256 VGPRs per wave) — and the
+// MFMAs consume them in issue order while the rest is still in flight.  The chunked loop above exposes one L2 / Infinity-Cache
+// round trip per 48 rows: the timestamp build (tools/lstm_timing.py) put the k loop at 11.9 of the 16.9 us of a timestep.  The W
+// pieces come from LDS through a small register ring (RW ahead).  Same k order as the chunked loop with rot = 0 => bitwise
+// reproducible.
+template <int NG, int NCOL, int PDS>
+__device__ __forceinline__ void panel_single(const float* __restrict__ xs, const float* wl, int kg0, int ln, int wcol, f32x4 (&acc)[NG]) {
+  constexpr int RW = 6;
+  float xb_[PDS][4];
+  const float* xb = xs + (long)kg0 * 4 * kLanes + ln;
+  const float* wb = wl + ((long)kg0 * NCOL + wcol) * 4;
+#pragma unroll
+  for (int j = 0; j < PDS; ++j)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) xb_[j][kk] = xb[(j * 4 + kk) * kLanes];
+  f32x4 aw[RW];
+#pragma unroll
+  for (int j = 0; j < RW && j < PDS; ++j) aw[j] = *reinterpret_cast<const f32x4*>(wb + j * NCOL * 4);
+#pragma unroll
+  for (int j = 0; j < PDS; ++j) {
+    const f32x4 a4 = aw[j % RW];
+    if (j + RW < PDS) aw[j % RW] = *reinterpret_cast<const f32x4*>(wb + (j + RW) * NCOL * 4);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float a = a4[kk], b = xb_[j][kk];
+#define NNL_MFMA_G(G) if constexpr (NG > G) acc[G] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[G], 4, G, 0);
+      NNL_MFMA_G(0) NNL_MFMA_G(1) NNL_MFMA_G(2) NNL_MFMA_G(3) NNL_MFMA_G(4) NNL_MFMA_G(5) NNL_MFMA_G(6) NNL_MFMA_G(7)
+#undef NNL_MFMA_G
+    }
+  }
+}
+
 // the workgroup's slice of a [rows][Kp] matrix -> LDS [Kp/4][ncol][4]; row_of(col) = source row (or -1: zeros)
 template <typename RowOf>
 __device__ __forceinline__ void load_slice(const float* __restrict__ w, int Kp, int ncol, float* wl, RowOf row_of) {
@@ -209,6 +243,11 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
   const int kg_per = p.Kp / (4 * kFwdWaves);              // Kp % 32 == 0: the eight waves get equal k ranges
   const int kg0 = wave * kg_per;
   const int rot = blockIdx.x;                             // any two workgroups of an XCD start at different chunks, however the XCDs are assigned
+  // all k rows of a wave in ONE request batch: a win only for short ranges (H = 400, 13 groups: 4.4 -> 3.9 us per step).  At H = 1150
+  // (36 groups, 144 loads per wave) it is 3x SLOWER than the chunked loop (k loop 11.9 -> 34 us, tools/lstm_timing.py): without the
+  // rotated chunk starts every workgroup of an XCD misses the same lines of the fresh slot at the same moment.  NNL_LSTM_SINGLE=2
+  // forces it for A/B runs.
+  const int single = ((p.single >= 1 && kg_per == 13) || (p.single == 2 && kg_per == 36)) ? kg_per : 0;
   const int ln = lane < B ? lane : 0, wcol = lane < 4 * NG ? lane : 4 * NG - 1;
   const long BH = (long)B * H, BG = (long)B * 4 * H, slot = (long)p.Kp * kLanes;
 #ifdef NNL_TAPS_TIMING
@@ -225,7 +264,11 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
     f32x4 acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(p.dbg & 1)) panel<NG, 4 * NG>(p.xT + t * slot, wl, kg0, kg_per, ln, wcol, rot, acc);
+    if (!(p.dbg & 1)) {
+      if (single == 36) panel_single<NG, 4 * NG, 36>(p.xT + t * slot, wl, kg0, ln, wcol, acc);
+      else if (single == 13) panel_single<NG, 4 * NG, 13>(p.xT + t * slot, wl, kg0, ln, wcol, acc);
+      else panel<NG, 4 * NG>(p.xT + t * slot, wl, kg0, kg_per, ln, wcol, rot, acc);
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -430,6 +473,7 @@ hipError_t nnl_lstm_persist_fwd(const float* gx, const float* w_hh_pad, const fl
   p.err = err;
   p.T = (int)T; p.B = (int)B; p.H = (int)H; p.Kp = (int)Kp; p.U = sh.U; p.NWG = sh.NWG;
   p.dbg = NNL_ENV_INT("NNL_LSTM_DBG", 0);
+  p.single = NNL_ENV_INT("NNL_LSTM_SINGLE", 1);
   hipError_t e = hipMemsetAsync(p.arrive, 0, sizeof(int) * T, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(exchange_prologue_kernel, dim3((unsigned)nnl_cdiv(H * kLanes, 256)), dim3(256), 0, s, h0, p.xT, (int)B, (int)H,
