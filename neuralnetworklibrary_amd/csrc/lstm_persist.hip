@@ -61,6 +61,7 @@ struct PersistFwd {
   int* err;
   int T, B, H, Kp, U, NWG;
   int dbg;              // timing experiments only (NNL_LSTM_DBG): 1 = no k loop, 2 = no grid wait
+  int pd;               // k groups per chunk of the forward k loop (NNL_LSTM_PD: 6 / 9 / 12 / 18; default 12)
   int single;           // 1: the single-chunk k loop where it is instantiated (NNL_LSTM_SINGLE, default 1)
 };
 
@@ -90,10 +91,9 @@ struct PersistBwd {
 // write-through stores by workgroups on every XCD, so the FIRST reader of a line in an XCD misses its L2; rotated starts spread
 // those misses over the whole slot at once and everybody else's chunks are L2 hits.  The order is fixed per workgroup => results
 // stay bitwise reproducible.
-template <int NG, int NCOL>
+template <int NG, int NCOL, int PD = 12>                  // PD k groups per chunk: 4 PD rows of 256 B in flight per wave, twice
 __device__ __forceinline__ void panel(const float* __restrict__ xs, const float* wl, int kg0, int nkg, int ln, int wcol, int rot,
                                       f32x4 (&acc)[NG]) {
-  constexpr int PD = 12;                                  // k groups per chunk: 48 rows of 256 B in flight per wave, twice
   float cur[PD][4], nxt[PD][4];
   const int nfull = nkg / PD;
   const float* xb = xs + (long)kg0 * 4 * kLanes + ln;
@@ -267,6 +267,9 @@ __global__ __launch_bounds__(kFwdBlock) void lstm_persist_fwd_kernel(PersistFwd 
     if (!(p.dbg & 1)) {
       if (single == 36) panel_single<NG, 4 * NG, 36>(p.xT + t * slot, wl, kg0, ln, wcol, acc);
       else if (single == 13) panel_single<NG, 4 * NG, 13>(p.xT + t * slot, wl, kg0, ln, wcol, acc);
+      else if (p.pd == 6) panel<NG, 4 * NG, 6>(p.xT + t * slot, wl, kg0, kg_per, ln, wcol, rot, acc);
+      else if (p.pd == 9) panel<NG, 4 * NG, 9>(p.xT + t * slot, wl, kg0, kg_per, ln, wcol, rot, acc);
+      else if (p.pd == 18) panel<NG, 4 * NG, 18>(p.xT + t * slot, wl, kg0, kg_per, ln, wcol, rot, acc);
       else panel<NG, 4 * NG>(p.xT + t * slot, wl, kg0, kg_per, ln, wcol, rot, acc);
     }
 #pragma unroll
@@ -474,6 +477,7 @@ hipError_t nnl_lstm_persist_fwd(const float* gx, const float* w_hh_pad, const fl
   p.T = (int)T; p.B = (int)B; p.H = (int)H; p.Kp = (int)Kp; p.U = sh.U; p.NWG = sh.NWG;
   p.dbg = NNL_ENV_INT("NNL_LSTM_DBG", 0);
   p.single = NNL_ENV_INT("NNL_LSTM_SINGLE", 1);
+  p.pd = NNL_ENV_INT("NNL_LSTM_PD", 12);
   hipError_t e = hipMemsetAsync(p.arrive, 0, sizeof(int) * T, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(exchange_prologue_kernel, dim3((unsigned)nnl_cdiv(H * kLanes, 256)), dim3(256), 0, s, h0, p.xT, (int)B, (int)H,
