@@ -16,8 +16,9 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
 }
 
 // source: [rows][256] floats per "image"; a tile iteration reads 64 rows x BK floats of A and of B at channel offset c0
-template <int BK, int MODE>   // MODE 0 REG, 1 DMA (2 buffers), 2 DMA3 (3 buffers)
-__global__ __launch_bounds__(256) void kloop(float* out, const float* __restrict__ src, int src_bytes, int iters) {
+template <int BK, int MODE, bool KSPLIT = false>   // MODE 0 REG, 1 DMA (2 buffers), 2 DMA3 (3 buffers); KSPLIT: each wave owns the whole
+__global__ __launch_bounds__(256) void kloop(  // 64x64 tile over a quarter of BK (4 accumulators, half the fragment reads)
+float* out, const float* __restrict__ src, int src_bytes, int iters) {
   constexpr int KC = BK / 4;                        // 16-B chunks per row
   constexpr int BKP = MODE == 0 ? BK + 4 : BK;      // padded rows only for the register-staged image
   constexpr int NBUF = MODE == 2 ? 3 : 2;
@@ -27,8 +28,8 @@ __global__ __launch_bounds__(256) void kloop(float* out, const float* __restrict
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
   const unsigned blk_base = (unsigned)(blockIdx.x % 61) * 128u * 1024u;     // 128 rows x 1 KB per block, L2-resident set
 
-  f32x16 acc, acc2;
-  for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
+  f32x16 acc, acc2, acc3, acc4;
+  for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; acc3[e] = 0.f; acc4[e] = 0.f; }
 
   // ---- fragment read addresses ----
   const int frow = lane & 31, fk = lane >> 5;       // row within the wave's 32, k half
@@ -78,7 +79,25 @@ __global__ __launch_bounds__(256) void kloop(float* out, const float* __restrict
       *reinterpret_cast<f32x4*>(lds + buf * TILE + (64 + row) * BKP + ch * 4) = rb[i];
     }
   };
+  auto ks_ptr = [&](int buf, int row) -> const float* {
+    const int chunk = wave * 2 + fk;
+    if (MODE == 0) return lds + buf * TILE + row * BKP + chunk * 4;
+    const int sw = (row >> 1) & 7;
+    return lds + buf * TILE + row * BK + ((chunk ^ sw) * 4);
+  };
   auto compute = [&](int buf) {
+    if (KSPLIT) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(ks_ptr(buf, frow)), a1 = *reinterpret_cast<const f32x4*>(ks_ptr(buf, 32 + frow));
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(ks_ptr(buf, 64 + frow)), b1 = *reinterpret_cast<const f32x4*>(ks_ptr(buf, 96 + frow));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc3, 0, 0, 0);
+        acc4 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc4, 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int kk = 0; kk < BK / 8; kk += 2) {
       const f32x4 a0 = *reinterpret_cast<const f32x4*>(frag_ptr(buf, 0, kk)), b0 = *reinterpret_cast<const f32x4*>(frag_ptr(buf, 1, kk));
@@ -136,7 +155,7 @@ __global__ __launch_bounds__(256) void kloop(float* out, const float* __restrict
   }
   // result: sum + a checksum cell per block so the variants can be compared for equality
   float s = 0.f;
-  for (int e = 0; e < 16; ++e) s += acc[e] + acc2[e];
+  for (int e = 0; e < 16; ++e) s += acc[e] + acc2[e] + acc3[e] + acc4[e];
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) atomicAdd(out + blockIdx.x, s);
 }
@@ -168,8 +187,12 @@ int main(int argc, char** argv) {
     tf(run("BK16 DMA (2 buf)", kloop<16, 1>, g), 16, g);
     tf(run("BK16 DMA3 (3 buf)", kloop<16, 2>, g), 16, g);
   }
+  for (int g : {1, 2, 3, 4}) {
+    tf(run("BK32 REG", kloop<32, 0>, g), 32, g);
+    tf(run("BK32 REG wave-k-split", kloop<32, 0, true>, g), 32, g);
+    tf(run("BK32 DMA wave-k-split", kloop<32, 1, true>, g), 32, g);
+  }
   for (int g : {4, 5}) {
-    if (g == 4) tf(run("BK32 REG", kloop<32, 0>, g), 32, g);
     tf(run("BK32 DMA (2 buf)", kloop<32, 1>, g), 32, g);
   }
   tf(run("BK32 DMA3 (3 buf)", kloop<32, 2>, 3), 32, 3);
