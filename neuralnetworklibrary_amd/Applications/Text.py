@@ -162,6 +162,8 @@ class WeightDropLSTM1(nn.Module):
     """Single-layer LSTM whose hidden-to-hidden matrix gets elementwise dropout (one mask per forward call, shared by
     all timesteps) — Text.py:477-513."""
 
+    nnl_stateful_forward = True        # the weight-drop seed of a call is drawn on the host (ops_text.lstm_layer): not replayable
+
     def __init__(self, input_size, hidden_size, drop):
         super().__init__()
         self.weight_drop = nn.Dropout(drop)
@@ -187,6 +189,8 @@ class LSTM_Encoder(nn.Module):
     """Embedding dropout -> num_layers x (WeightDropLSTM1 -> locked hidden dropout), carried hidden state
     (Text.py:515-551).  `fixed_masks` (dict with 'emb_rows', 'emb_locked', 'weights'[l], 'hidden'[l]) pins the dropout
     masks for parity tests."""
+
+    nnl_stateful_forward = True        # carries (h, c) between minibatches on the Python side: Learner.use_graphs() keeps such steps eager
 
     def __init__(self, vocab_size, emb_dim, hidden_size, num_layers, pad_token, drops, bs):
         super().__init__()

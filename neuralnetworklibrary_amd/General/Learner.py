@@ -223,7 +223,7 @@ class Learner(object):
         self.optimizer = Optimizer(opt_dict[optimizer], self.model) if isinstance(optimizer, str) else optimizer
         self.bn_frozen = None
         self.grad_sync = None
-        self._graph_warmup, self._graphs = None, {}
+        self._graph_warmup, self._graphs, self._graph_stateless = None, {}, None
         self._loss_host, self._loss_event = None, None
         self._dp_weight, self._dp_equal_shards = 1.0, False
         # launch-bound heads (CollabFilterNet, StructuredDataNet: ~100 tiny launches per step, 2.2 - 2.4x slower eager than replayed)
@@ -280,9 +280,10 @@ class Learner(object):
         filtering, structured data: ~100 tiny launches per step) the step time is the host's launch rate otherwise.
         Learning rate / weight decay / momentum / betas / Adam bias corrections are read from device memory by the fused
         optimizer kernel, so schedules keep working.  Only for models whose forward is stateless between minibatches
-        (NOT the language model: its carried hidden state is Python-side) and tensor-valued targets; a minibatch of another
-        shape (the ragged last one) runs eagerly.  Invalidated by freeze / unfreeze / load."""
-        self._graph_warmup, self._graphs, self._dp_graph_ok = (int(warmup) if flag else None), {}, None
+        (NOT the language model: its carried hidden state is Python-side — modules marked `nnl_stateful_forward` keep the step
+        eager) and tensor-valued targets; a minibatch of another shape (the ragged last one) runs eagerly.  Invalidated by
+        freeze / unfreeze / load."""
+        self._graph_warmup, self._graphs, self._dp_graph_ok, self._graph_stateless = (int(warmup) if flag else None), {}, None, None
         return self
 
     def _reattach(self):
@@ -623,6 +624,13 @@ class Learner(object):
         leaves = _tensor_leaves(x_batch) + _tensor_leaves(y_batch)
         if any(t is None for t in leaves) or not self.optimizer.graph_capturable() or not self.model.training:
             return None
+        if getattr(self, '_graph_stateless', None) is None:
+            # a forward that carries Python-side state from one minibatch to the next (the language model's hidden state,
+            # Text.py:547-550) or draws per-call host randomness (the weight-drop seed) cannot be replayed: such modules mark
+            # themselves `nnl_stateful_forward` and the step stays eager whatever use_graphs() was asked for
+            self._graph_stateless = not any(getattr(m, 'nnl_stateful_forward', False) for m in self.model.modules())
+        if not self._graph_stateless:
+            return None
         from ..dist import drop_ctx
         if drop_ctx.enabled:
             # keyed masks bake (step, request index) — Python ints — into the captured kernels' arguments: a replay would
@@ -736,7 +744,7 @@ class Learner(object):
 
         if swa_freq:
             self.model = swa_model
-            self._graphs = {}                         # captured steps point at the replaced model's parameters
+            self._graphs, self._graph_stateless = {}, None   # captured steps point at the replaced model's parameters
 
     def _print_batch(self, j, debiased, loss, metrics, x_batch, y_batch, dt):
         if _rank() != 0:

@@ -150,7 +150,10 @@ def test_g7_language_model_hip():
 
 
 @pytest.mark.gpu
-def test_g7_language_model_hip_learner_steps():
+@pytest.mark.parametrize('ask_for_graphs', [False, True])
+def test_g7_language_model_hip_learner_steps(ask_for_graphs):
+    """ask_for_graphs: Learner.use_graphs() on a language model must NOT capture the step (the carried hidden state and the
+    weight-drop seed live on the host: LSTM_Encoder / WeightDropLSTM1 are marked nnl_stateful_forward) — same golden losses, eagerly."""
     from neuralnetworklibrary_amd.Applications.Text import RegSeqCrossEntropyLoss
     from neuralnetworklibrary_amd.General.Learner import Learner
     g = load_golden('g7_text')
@@ -159,11 +162,14 @@ def test_g7_language_model_hip_learner_steps():
     d.train_dl, d.val_dl = batches, batches
     learner = Learner('/tmp/nnl_test_g7', d, net, optimizer='Adam', loss_func=RegSeqCrossEntropyLoss(2.0, 1.0))
     learner.init_optimizer(wd=1e-6, clip=0.4)
+    if ask_for_graphs:
+        learner.use_graphs(True, warmup=0)
     net.train()
     losses = [learner.train1minibatch(x, y, [1e-3, 2e-3], betas_batch=(0.8, 0.99)) for x, y in batches]
     assert_close(np.array(losses), g['c.step_losses'], 1e-4, 1e-6, 'step losses')
     assert_close(np.array([p.double().abs().sum().item() for p in net.parameters()]), g['c.after.abs_sums'], 1e-4, 1e-7, 'abs sums')
     assert_close(net.enc.word_embed.embed.weight, g['c.after.emb'], 1e-3, 1e-4, 'embedding after 2 steps')
+    assert learner._graphs == {}, 'a stateful forward was captured'
 
 
 @pytest.mark.gpu
