@@ -69,6 +69,15 @@ static bool taps_dma(int bk, const IgemmTapsParams&) {
   return bk == 16 ? (m & 1) != 0 : (m & 2) != 0;
 }
 
+// Two tiles in flight (PF = 2, igemm_taps.h) for the 64x64 tile: NNL_IGEMM_PF2 bit 0 = BK 16 launches (default ON), bit 1 = BK 32
+// launches (default off).  Measured per ResNet-34 layer at 64 images (bench_conv.py --ab NNL_IGEMM_PF2=0,1,2,3,
+// profiles/r3_pf2_bs64.log): BK 16 (the 28x28 / C = 128 stage) fwd 107.0 -> 111.7 TF/s, dgrad 112.7 -> 116.7; BK 32 needs 148
+// VGPRs (three workgroups per CU instead of four) and LOSES 3-8 % on every stride-1 layer (l1 107 -> 104, l4 117 -> 109).
+static bool taps_pf2(int bk, const IgemmTapsParams&) {
+  const int m = NNL_ENV_INT("NNL_IGEMM_PF2", 1);
+  return bk == 16 ? (m & 1) != 0 : (m & 2) != 0;
+}
+
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
   p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
@@ -79,6 +88,13 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
   if constexpr (BM == 64 && BN == 64) {
     if (taps_dma(BK, p)) {
       hipLaunchKernelGGL((igemm_taps_kernel<64, 64, BK, 2, 2, false, 0, true>), dim3(gx, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
+      NNL_CHECK_LAUNCH();
+      return NNL_OK;
+    }
+  }
+  if constexpr (BM == 64 && BN == 64) {
+    if (taps_pf2(BK, p)) {
+      hipLaunchKernelGGL((igemm_taps_kernel<64, 64, BK, 2, 2, true, 0, false, 2>), dim3(gx, p.ksplit > 1 ? p.ksplit : 1), dim3(256), 0, s, p);
       NNL_CHECK_LAUNCH();
       return NNL_OK;
     }
@@ -200,6 +216,10 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counte
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk != 32 && taps_dma(16, p))
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk == 32 && taps_pf2(32, p))
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true, 0, false, 2>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk != 32 && taps_pf2(16, p))
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, true, 0, false, 2>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk == 32 && p.variant == 1)
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk == 32)

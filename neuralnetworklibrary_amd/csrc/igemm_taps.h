@@ -111,8 +111,14 @@ __device__ __forceinline__ float nnl_sigmoid(float x) { return 1.f / (1.f + expf
 // Three LDS buffers keep one tile in flight across the barrier (counted vmcnt, raw s_barrier).
 #define NNL_LDSP(ptr) ((__attribute__((address_space(3))) void*)(ptr))
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0, bool DMA = false>
-__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
+// PF = 2 (register staging only): TWO tiles in flight — the buffer loads of tile kt+2 are issued while tile kt is computed and
+// land in a second register set; tile kt+1 (requested one iteration earlier) is written to LDS at the end of the iteration.  A
+// request then has two iterations (~2.5 us with three co-resident workgroups) to come back instead of one: with 64-channel
+// layers almost every A tile contains a first-touch L2 miss (12 % of the lines, 32 lines per wave and tile), and the
+// co-resident workgroups of a CU, phase-locked by the shared MFMA pipe, all wait for theirs at the same time.
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0, bool DMA = false, int PF = 1>
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
+  static_assert(PF == 1 || (PF == 2 && !DMA), "PF = 2 is a register-staging variant");
   static_assert(EPI == 0 || (BM == 64 && BN == 64), "the LSTM epilogue is written for the 64x64 tile");
   static_assert(WGM * WGN == 4 && BK % 8 == 0, "config");
   static_assert(!DMA || (BM == 64 && BN == 64 && EPI == 0 && (BK == 16 || BK == 32)), "LDS-DMA staging: 64x64 tile only");
@@ -438,6 +444,51 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 3 : 4) void igemm_tap
       cur ^= 1;
     }
     __syncthreads();
+  } else if constexpr (PF == 2) {
+    f32x4 ra2[PA], rb2[PB];
+    auto load_tile2 = [&](int c0) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra2[i] = buf_load4(ra_src, a_voff[i], (unsigned)c0 * 4u);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb2[i] = buf_load4(rb_src, b_off[i], b_tap + (unsigned)c0 * 4u);
+    };
+    auto store_tile2 = [&](int buf) {
+      float* As = lds[buf];
+      float* Bs = As + BM * BKP;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(As + (lrow + i * RPP) * BKP + kc * 4) = ra2[i];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Bs + (lrow + i * RPP) * BKP + kc * 4) = rb2[i];
+    };
+    if (nk > 0) {
+      set_tap(t_nx);
+      load_tile(c_nx, 0);
+      store_tile(0);                             // tile 0 -> LDS[0]
+      if (nk > 1) advance();
+      load_tile(c_nx, 0);                        // tile 1 -> set A, in flight (nk == 1: tile 0 again, never used)
+    }
+    __syncthreads();
+    NNL_TSTAMP(1);
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt += 2) {
+      if (kt + 2 < nk) advance();
+      load_tile2(c_nx);                          // tile kt+2 -> set B
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tile(cur ^ 1);                       // set A = tile kt+1 (requested an iteration ago)
+      __syncthreads();
+      cur ^= 1;
+      if (kt + 1 >= nk) break;
+      if (kt + 3 < nk) advance();
+      load_tile(c_nx, 0);                        // tile kt+3 -> set A
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      store_tile2(cur ^ 1);                      // set B = tile kt+2
+      __syncthreads();
+      cur ^= 1;
+    }
   } else {
   if (nk > 0) {
     set_tap(t_nx);
