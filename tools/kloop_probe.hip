@@ -160,6 +160,87 @@ float* out, const float* __restrict__ src, int src_bytes, int iters) {
   if (lane == 0) atomicAdd(out + blockIdx.x, s);
 }
 
+// XB: the register-staged BK32 loop with the MFMA block split AROUND the barrier.  The fragments of the first 16 k of tile i+1 are
+// read right after the barrier of iteration i while the last four MFMAs of tile i (operands already in registers) are still to be
+// issued, and the LDS writes of tile i+1 sit between the two MFMA blocks — a wave always has independent MFMAs queued across its
+// ds_write -> barrier -> ds_read turnaround.  Same arithmetic as kloop<32, 0> (same accumulation order per accumulator).
+__global__ __launch_bounds__(256) void kloop_xb(float* out, const float* __restrict__ src, int src_bytes, int iters) {
+  constexpr int BK = 32, KC = 8, BKP = 36, TILE = 128 * BKP;
+  __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, src_bytes, 0x00020000);
+  const unsigned blk_base = (unsigned)(blockIdx.x % 61) * 128u * 1024u;
+  f32x16 acc, acc2;
+  for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
+  const int frow = lane & 31, fk = lane >> 5;
+  const float* fa = lds + (wm * 32 + frow) * BKP + fk * 4;            // + buf * TILE + kk * 8
+  const float* fb = lds + (64 + wn * 32 + frow) * BKP + fk * 4;
+  constexpr int RPP = 256 / KC, PASSES = 64 / RPP;                    // 32 rows per pass, 2 passes
+  f32x4 ra[PASSES], rb[PASSES];
+  auto issue = [&](int it) {
+    const unsigned c0 = (unsigned)((it * BK) & 255) * 4u;
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const unsigned row = tid / KC + i * RPP, ch = tid % KC;
+      ra[i] = buf_load4(rs, blk_base + row * 1024u + ch * 16u, c0);
+      rb[i] = buf_load4(rs, blk_base + (64u + row) * 1024u + ch * 16u, c0);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+      const int row = tid / KC + i * RPP, ch = tid % KC;
+      *reinterpret_cast<f32x4*>(lds + buf * TILE + row * BKP + ch * 4) = ra[i];
+      *reinterpret_cast<f32x4*>(lds + buf * TILE + (64 + row) * BKP + ch * 4) = rb[i];
+    }
+  };
+  f32x4 a0, b0, a1, b1, a2, b2, a3, b3;                               // k groups 0,1 (R0) and 2,3 (R1)
+  auto read_h0 = [&](int buf) {
+    a0 = *reinterpret_cast<const f32x4*>(fa + buf * TILE); b0 = *reinterpret_cast<const f32x4*>(fb + buf * TILE);
+    a1 = *reinterpret_cast<const f32x4*>(fa + buf * TILE + 8); b1 = *reinterpret_cast<const f32x4*>(fb + buf * TILE + 8);
+  };
+  auto read_h1 = [&](int buf) {
+    a2 = *reinterpret_cast<const f32x4*>(fa + buf * TILE + 16); b2 = *reinterpret_cast<const f32x4*>(fb + buf * TILE + 16);
+    a3 = *reinterpret_cast<const f32x4*>(fa + buf * TILE + 24); b3 = *reinterpret_cast<const f32x4*>(fb + buf * TILE + 24);
+  };
+  issue(0); commit(0); __syncthreads();
+  read_h0(0);
+  int cur = 0;
+  for (int it = 0; it < iters; ++it) {
+    issue(it + 1);
+    read_h1(cur);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    commit(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], b2[t], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[t], b3[t], acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    read_h0(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 2; t < 4; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[t], b2[t], acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[t], b3[t], acc2, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    cur ^= 1;
+  }
+  float sum = 0.f;
+  for (int e = 0; e < 16; ++e) sum += acc[e] + acc2[e];
+  for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) atomicAdd(out + blockIdx.x, sum);
+}
+
 int main(int argc, char** argv) {
   const int src_floats = 64 * 128 * 256 + 4096;
   std::vector<float> h(src_floats);
@@ -188,6 +269,7 @@ int main(int argc, char** argv) {
     tf(run("BK16 DMA3 (3 buf)", kloop<16, 2>, g), 16, g);
   }
   for (int g : {1, 2, 3, 4}) {
+    tf(run("BK32 REG cross-barrier MFMA split", kloop_xb, g), 32, g);
     tf(run("BK32 REG", kloop<32, 0>, g), 32, g);
     tf(run("BK32 REG wave-k-split", kloop<32, 0, true>, g), 32, g);
     tf(run("BK32 DMA wave-k-split", kloop<32, 1, true>, g), 32, g);
