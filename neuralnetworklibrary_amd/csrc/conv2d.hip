@@ -4,6 +4,7 @@
 // Layout: activations NHWC, filters KRSC (see include/nnl.h).  MFMA-bound: 2*N*P*Q*K*R*S*C flops per pass.
 #include "igemm_kernels.h"
 #include "igemm_taps.h"
+#include "wino.h"
 #include "igemm_wgrad.h"
 
 #ifdef NNL_TAPS_TIMING
@@ -712,18 +713,50 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
   return NNL_OK;
 }
 
+// Which kernel serves a 3x3 / stride 1 / pad 1 problem (in = [N][H][W][Cin], Nc output channels)?  NNL_CONV_WINO: 0 never the
+// Winograd kernel, 2 always (where it applies), 1 (default) by predicted time.  Both planners share one cost model (us per k
+// iteration of a CU's resident workgroups); measured against it (tools/bench_conv.py --ab NNL_CONV_WINO=0,2 at 8 / 16 / 32 / 64
+// images, profiles/r3_wino_*.log) the Winograd iteration costs 1.18x (BK 16) / 1.08x (BK 32) the direct one (two A loads and an add per
+// staged element, single accumulator chains: folded into nnl_wino_plan_time_us), both launches carry ~6 us the model does not see, and the filter transform adds a launch (3 us)
+// plus 21 * Cin * Nc * 4 bytes of traffic.  A 3 % margin keeps coin-flip cases on the direct kernel.
+static bool wino_preferred(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
+  if (!nnl_wino_ok(N, H, W, Cin, Nc, R, S, stride, pad)) return false;
+  if (NNL_ENV_INT("NNL_CONV_WINO", 1) == 2) return true;
+  const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
+  const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
+  return t_w < 0.97 * t_d;
+}
+
+// debug / tuning: the two planners' predicted launch times (us) for a 3x3 / stride 1 / pad 1 problem: out[0] direct, out[1] Winograd
+extern "C" int nnl_debug_conv_plan_times(int N, int H, int W, int Cin, int Nc, double* out) {
+  out[0] = plan_balance((long)N * H * W, Nc, Cin, 9).t_us;
+  out[1] = nnl_wino_plan_time_us(N, H, W, Cin, Nc);
+  return wino_preferred(N, H, W, Cin, Nc, 3, 3, 1, 1) ? 1 : 0;
+}
+
+// (the larger of the direct kernel's slabs and the Winograd path's transformed filter + slabs: either may run, see wino.h)
 extern "C" size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g) {
   if (!g || check_geom(g, "conv2d_fwd_workspace_bytes")) return 0;
   const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
   if (!taps_ok(a_elems, b_elems, g->C, g->R * g->S)) return 0;
-  return balance_workspace_bytes((long)g->N * g->P * g->Q, g->K, g->C, g->R * g->S);
+  size_t b = balance_workspace_bytes((long)g->N * g->P * g->Q, g->K, g->C, g->R * g->S);
+  if (wino_preferred(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad)) {
+    const size_t wb = nnl_wino_workspace_bytes(g->N, g->H, g->W, g->C, g->K);
+    if (wb > b) b = wb;
+  }
+  return b;
 }
 
 extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
   if (!g || check_geom(g, "conv2d_dgrad_workspace_bytes") || g->stride != 1) return 0;
   const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
   if (!taps_ok(a_elems, b_elems, g->K, g->R * g->S)) return 0;
-  return balance_workspace_bytes((long)g->N * g->H * g->W, g->C, g->K, g->R * g->S);
+  size_t b = balance_workspace_bytes((long)g->N * g->H * g->W, g->C, g->K, g->R * g->S);
+  if (wino_preferred(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad)) {
+    const size_t wb = nnl_wino_workspace_bytes(g->N, g->P, g->Q, g->K, g->C);
+    if (wb > b) b = wb;
+  }
+  return b;
 }
 
 extern "C" int64_t nnl_conv2d_tile_counters(void) { return kTileCounters; }
@@ -744,6 +777,18 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
   p.M = g->N * g->P * g->Q; p.Nc = g->K; p.Kg = g->R * g->S * g->C; p.relu = relu;
   NnlProfScope prof(NNL_PROF_CONV_FWD, s, 2.0 * p.M * (double)p.Nc * p.Kg);
   const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
+  if (relu != 2 && workspace != nullptr && wino_preferred(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad) &&
+      workspace_bytes >= nnl_wino_workspace_bytes(g->N, g->H, g->W, g->C, g->K)) {
+    // 3x3 / stride 1 / pad 1: fused 1-D Winograd F(2,3) (wino.hip) — 1.5x fewer MFMA k-steps per output
+    WinoProblem wq{};
+    wq.in = x; wq.filt = w; wq.out = y; wq.bias = bias; wq.add = nullptr;
+    wq.N = g->N; wq.H = g->H; wq.W = g->W; wq.Cin = g->C; wq.Nc = g->K; wq.relu = relu; wq.flip = 0;
+    const bool stats = bn_partials && bn_pivot && bn_rows;
+    wq.bn_part = stats ? bn_partials : nullptr; wq.bn_pivot = bn_pivot;
+    st = nnl_wino_launch(wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
+    if (st == NNL_OK && stats) *bn_rows = nnl_wino_bn_rows(g->N, g->H, g->W);
+    return st;
+  }
   if (taps_ok(a_elems, b_elems, g->C, g->R * g->S)) {
     IgemmTapsParams q{};
     q.a = x; q.b = w; q.y = y; q.bias = bias; q.add = nullptr;
@@ -841,6 +886,14 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
   p.M = g->N * g->H * g->W; p.Nc = g->C; p.Kg = g->R * g->S * g->K; p.relu = 0;
   NnlProfScope prof(NNL_PROF_CONV_DGRAD, s, 2.0 * g->N * (double)g->P * g->Q * g->K * g->R * g->S * g->C);
   const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
+  if (workspace != nullptr && wino_preferred(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad) &&
+      workspace_bytes >= nnl_wino_workspace_bytes(g->N, g->P, g->Q, g->K, g->C)) {
+    // stride-1 dgrad of a 3x3 / pad 1 filter = the same convolution over dy with the flipped, transposed filter (wino.hip)
+    WinoProblem wq{};
+    wq.in = dy; wq.filt = wt; wq.out = dx; wq.bias = nullptr; wq.add = addend;
+    wq.N = g->N; wq.H = g->P; wq.W = g->Q; wq.Cin = g->K; wq.Nc = g->C; wq.relu = 0; wq.flip = 1;
+    return nnl_wino_launch(wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
+  }
   if (taps_ok(a_elems, b_elems, g->K, g->R * g->S) && (g->stride == 1 || g->stride == 2)) {
     IgemmTapsParams q{};
     q.a = dy; q.b = wt; q.y = dx; q.bias = nullptr; q.add = addend;

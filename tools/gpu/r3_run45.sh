@@ -1,0 +1,18 @@
+#!/bin/bash
+# Winograd path on by default: the whole GPU suite + smoke + full bench
+set -x
+cd /root/repo; export TMPDIR=/tmp
+timeout -k 10 1100 python -m pytest tests -m gpu -q > gpurun_out/r3_t45.log 2>&1; echo "pytest rc=$?"
+tail -8 gpurun_out/r3_t45.log | cut -c1-300
+timeout -k 10 200 python __graft_entry__.py smoke > gpurun_out/r3_smoke45.log 2>&1; echo "smoke rc=$?"
+tail -2 gpurun_out/r3_smoke45.log
+timeout -k 10 600 python bench.py > gpurun_out/r3_bench45.json.log 2>gpurun_out/r3_bench45.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+for l in open('gpurun_out/r3_bench45.json.log'):
+    if l.startswith('{'):
+        d=json.loads(l)
+        print('headline',d['value'],d['ms_per_step'],d['roofline']['frac'], d['roofline']['by_kind'])
+        print({k:(v['ms_per_step']) for k,v in d['configs'].items()})
+        print({k:v.get('hipgraph_ms_per_step') for k,v in d['strong_scaling_proxy'].items() if isinstance(v,dict)})
+PY
