@@ -134,6 +134,22 @@ size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g);   /* optional
  * accumulation kernel.  A stride-2 dgrad with even H and W runs its four output-parity classes in one launch. */
 int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
                      void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream);
+/* ---- 3x3 / stride 1 / pad 1 on the fused Winograd F(2,3) kernel (csrc/wino.hip) -------------------------------------------
+ * nnl_conv2d_fwd and the stride-1 nnl_conv2d_dgrad use it on their own whenever the planner predicts it to be faster than the
+ * direct implicit-GEMM kernel (NNL_CONV_WINO: 0 never, 1 by predicted time = default, 2 wherever it applies); results agree
+ * with the direct kernel to fp32 rounding (measured 6e-6 .. 1e-5 absolute on O(1) outputs, tools/bench_wino.py).  The three
+ * entry points below expose the kernel and the planners directly for the A/B tools and tests:
+ *   out[N,H,W,K] = conv3x3_pad1(x[N,H,W,C], filt) (+ bias[K]) (+ add[N,H,W,K]) (ReLU when relu == 1); flip == 0: filt = w[K,3,3,C];
+ *   flip == 1: filt = wt[K,3,3,C] read as wt[.,2-r,2-s,.] (the dgrad filter: x = dy, K = C_in of the layer, wt = W^T[C,R,S,K]).
+ *   ws: nnl_debug_conv_wino_workspace_bytes bytes; counters: n_counters zeroed int32 (zero again on return) or NULL (plain grid);
+ *   bn_part / bn_pivot (both or neither): BatchNorm partial statistics as for nnl_conv2d_fwd, one per 64 output pairs.
+ * nnl_debug_conv_plan_times: out[0] / out[1] = predicted launch time (us) of the direct / the Winograd kernel for that problem;
+ *   returns 1 when the dispatcher would pick the Winograd kernel, else 0. */
+size_t nnl_debug_conv_wino_workspace_bytes(int N, int H, int W, int C, int K);
+int nnl_debug_conv_wino_fwd(const float* x, const float* filt, const float* bias, const float* add, float* y, void* ws,
+                            size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
+                            int H, int W, int C, int K, int relu, int flip, void* stream);
+int nnl_debug_conv_plan_times(int N, int H, int W, int C, int K, double* out);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
  * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */
 size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g);

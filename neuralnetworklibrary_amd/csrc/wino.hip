@@ -451,7 +451,7 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
 // debug / A-B entry (tools/bench_wino.py): ws as nnl_wino_workspace_bytes; counters: >= tiles zeroed int32 or null
 extern "C" size_t nnl_debug_conv_wino_workspace_bytes(int N, int H, int W, int C, int K) { return nnl_wino_workspace_bytes(N, H, W, C, K); }
 extern "C" int nnl_debug_conv_wino_fwd(const float* x, const float* w, const float* bias, const float* add, float* y, void* ws,
-                                       size_t ws_bytes, int* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
+                                       size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
                                        int H, int W, int C, int K, int relu, int flip, void* stream) {
   NNL_CHECK_ARG(nnl_wino_ok(N, H, W, C, K, 3, 3, 1, 1), "wino: unsupported shape");
   WinoProblem q{};

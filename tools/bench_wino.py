@@ -30,12 +30,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bs', type=int, default=64)
     args = ap.parse_args()
-    f = lib.nnl_debug_conv_wino_fwd
-    f.restype = C.c_int
-    f.argtypes = [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    f = lib.nnl_debug_conv_wino_fwd                    # (signatures: neuralnetworklibrary_amd/_lib.py)
     fw = lib.nnl_debug_conv_wino_workspace_bytes
-    fw.restype = C.c_size_t
-    fw.argtypes = [C.c_int] * 5
     dev = torch.device('cuda:0')
     counters = torch.zeros(1 << 16, dtype=torch.int32, device=dev)
     for name, Cc, K, H in [('l1', 64, 64, 56), ('l2', 128, 128, 28), ('l3', 256, 256, 14), ('l4', 512, 512, 7), ('odd', 64, 128, 9)]:
