@@ -576,7 +576,7 @@ def run_config(name, device, world, rank, clock, steps, warmup, cpu):
         rf['algorithmic_tflop_per_step'] = LM_MFLOP_PER_TOKEN * 1e6 * wl.units_per_step / 1e12
         rf['whole_step_tflops'] = round(rf['algorithmic_tflop_per_step'] / (ms * 1e-3), 2)
     elif name == 'retinanet':
-        rf = mfma_roofline(prof, n_prof, FLOP_KINDS, 'igemm_taps / igemm_wgrad (ResNet-50 + FPN + head convolutions: fwd, dgrad, wgrad)')
+        rf = mfma_roofline(prof, n_prof, FLOP_KINDS, 'igemm_taps / wino / igemm_wgrad (ResNet-50 + FPN + head convolutions: fwd, dgrad, wgrad)')
         rf['algorithmic_tflop_per_step'] = RETINA_GFLOP_PER_IMAGE * 1e9 * bs / 1e12
         rf['whole_step_tflops'] = round(rf['algorithmic_tflop_per_step'] / (ms * 1e-3), 2)
         if 'retina_loss' in prof:
@@ -732,8 +732,10 @@ def worker(args):
     last_loss = wl.loss
     n_prof = min(args.steps, 10)
     prof = profile_kinds(wl, n_prof)
-    roofline = mfma_roofline(prof, n_prof, kernel='igemm_taps_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: '
-                                                  'fwd, dgrad, wgrad; incl. their slab reduces)')
+    roofline = mfma_roofline(prof, n_prof, kernel='igemm_taps_kernel / wino_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: '
+                                                  'fwd, dgrad, wgrad; incl. their slab reduces and filter transforms)')
+    roofline['note'] = ('achieved = ALGORITHMIC convolution flop (2 N P Q K R S C per pass, SURVEY.md 8d) / measured time: the 3x3 stride-1 '
+                        'forward / dgrad launches run a fused Winograd F(2,3) kernel that issues 1.5x fewer MFMA multiplies than that count')
     roofline['conv_ms_per_step'] = roofline['kernel_ms_per_step']
     roofline['traffic'], src = committed_traffic(args.bs, args.sz, world)
     if src:

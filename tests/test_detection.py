@@ -231,12 +231,13 @@ FLOORED_TENSORS = ('regressor.',)          # see the end of the test below
 
 # Gradient SLICES (1024 elements of one weight gradient, eval mode) are the noisiest quantity this file checks: one ReLU gate that
 # two correct fp32 evaluations set differently moves a slice by ~1e-3 of its norm (docstring of assert_within_reference_gap), and
-# which gates sit within rounding of zero changes with every legitimate change of summation order.  Measured on the GPU box,
-# err / (3 x gap + 1e-3 x norm) over the 24 slices: direct implicit-GEMM kernels worst 0.93, with the Winograd F(2,3) path
-# for the 3x3 convolutions worst 1.05 (layer2.0.conv2.weight: 2.4e-3 of its norm from fp64, the CPU oracle's own fp32 run 4.4e-4)
-# — both kernels within 1e-5 of each other and of fp64 on every ACTIVATION of the net.  The slices therefore get a 2e-3 floor; the
-# activations, the loss and the per-parameter gradient norms keep 1e-3.
-GRAD_SLICE_FLOOR = 2e-3
+# which gates sit within rounding of zero changes with every legitimate change of summation order.  The test prints the worst
+# five ratios err / (3 x gap + floor x norm).  Measured on the GPU box at G12's size (64 x 64 input: every 3x3 convolution is
+# tiny, so the dispatcher keeps them on the direct kernel): worst 0.37 at a floor of 2e-3.  With the Winograd kernel FORCED onto
+# these tiny maps (NNL_CONV_WINO=2) the worst slice is fpn.P5_1.weight at 1.37 (2e-3 floor) although the two kernels agree to
+# 1e-6 on every single convolution of that size (tools/wino_debug.py) — gate flips on a 2x2 map, not arithmetic error; the
+# production sizes (G13b, G15: 20- / 10-step loss curves) run the Winograd kernel and hold their 1e-3.
+GRAD_SLICE_FLOOR = 1e-3
 
 
 def slice_gap_ratio(got, g, key, slack, floor, host32):
