@@ -338,7 +338,9 @@ WPlan wino_plan(long M2, int Nc, int C) {
   WPlan best{};
   const long gm = nnl_cdiv(M2, 64), gn = nnl_cdiv(Nc, 64), T = gm * gn;
   const int e_bk = NNL_ENV_INT("NNL_WINO_BK", 0);
-  best.bk = (e_bk == 16 || e_bk == 32) ? e_bk : ((C % 32 == 0 && T < 600) ? 32 : 16);
+  // BK 32 where the per-tap channel loop is short (C = 64: 134.5 -> 137.5 TF/s) or the grid small (7x7 stage: 116 -> 125); BK 16
+  // otherwise (28x28 / 14x14 stages: 144 / 151 against 141 / 147) — tools/bench_conv.py --ab NNL_WINO_BK=16,32
+  best.bk = (e_bk == 16 || e_bk == 32) ? e_bk : ((C % 32 == 0 && (C == 64 || T < 300)) ? 32 : 16);
   if (C % best.bk != 0) best.bk = 16;
   const int bk = best.bk;
   const long I = 12L * (C / bk);
