@@ -4,6 +4,7 @@ ResNet-34 stage shape, through the debug entry nnl_debug_conv_wino_fwd.   python
 import argparse
 import ctypes as C
 import json
+import os
 import sys
 
 import torch
@@ -54,6 +55,7 @@ def main():
             check(f(ptr(xin), ptr(filt), ptr(bias), ptr(add), ptr(out), ptr(ws), wsb, ptr(counters), counters.numel(),
                     ptr(part) if bn else None, ptr(piv) if bn else None, N, H, H, cc, kk, relu, flip, stream()))
 
+        os.environ['NNL_CONV_WINO'] = '0'; lib.nnl_reload_env()       # the references below: the DIRECT implicit-GEMM kernel
         with torch.no_grad():
             ref = ops.conv2d(x, w, b, 1, 1, relu=True).permute(0, 2, 3, 1).contiguous()
         flops = 2.0 * N * H * H * K * 9 * Cc
