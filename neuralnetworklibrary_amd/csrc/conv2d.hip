@@ -489,7 +489,7 @@ struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split, kg; };
 // cannot hide the load latency; the slab reduce moves (splits+1) x |dw| bytes.  The smaller tiles pay a measured
 // efficiency factor (bench_conv.py, NNL_WGRAD_TILE sweep) but give short pixel ranges (1x1/2 shortcut convs: 12544 pixels)
 // enough workgroups to fill 256 CUs.
-WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
+WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     // != 0: square tiles only, bn must divide it (Winograd columns)
   struct Cand { int bm, bn; double cost; };                               // cost: time per FLOP relative to the 128x128 tile
   static const Cand cands[4] = {{128, 128, 1.00}, {128, 64, 1.08}, {64, 128, 1.08}, {64, 64, 1.10}};
   const int forced = NNL_ENV_INT("NNL_WGRAD_TILE", -1);                    // tuning hook: index into cands
@@ -498,7 +498,9 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   double best_t = 1e300;
   for (int ci = 0; ci < 4; ++ci) {
     const Cand& c = cands[ci];
-    if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
+    if (square_bn_divides != 0) {
+      if (c.bm != c.bn || square_bn_divides % c.bn != 0 || (c.bm == 128 && Mc < 128)) continue;
+    } else if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
     const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
     const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
     const int f_sp = NNL_ENV_INT("NNL_WGRAD_SPLITS", 0);                  // A/B hook: force the split count
@@ -526,6 +528,7 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp) {
   }
   if (pl.bm == 0) {                                                       // more tiles than 5 per CU even unsplit: largest legal tile
     pl.bm = Mc >= 128 ? 128 : 64; pl.bn = (Nc >= 128 && pl.bm == 128) ? 128 : 64;
+    if (square_bn_divides != 0 && square_bn_divides % pl.bn != 0) { pl.bm = 64; pl.bn = 64; }
     pl.grid_m = (int)nnl_cdiv(Mc, pl.bm); pl.grid_n = (int)nnl_cdiv(Nc, pl.bn);
     pl.splits = 1; pl.k_per_split = (int)(nnl_cdiv(Kp, 32) * 32);
   }
@@ -614,6 +617,89 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
     else NNL_WGRAD_LAUNCH(64, 64, 16, false, 1);
   }
 #undef NNL_WGRAD_LAUNCH
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+// dW [K][3][3][C] from the Winograd-domain slabs dU [splits][K][4][3][C] (igemm_wgrad_kernel<..., WINO>): the slabs are summed in
+// index order (bitwise reproducible), then dg0 = dU0 + (dU1 + dU2)/2, dg1 = (dU1 - dU2)/2, dg2 = (dU1 + dU2)/2 + dU3.
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, long n4,
+                                                                 int C4, int splits, long slab4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // over (k, r, c4)
+  if (i >= n4) return;
+  const long c4 = i % C4, kr = i / C4, r = kr % 3, k = kr / 3;
+  const f32x4* src = reinterpret_cast<const f32x4*>(part) + (k * 12 + r) * C4 + c4;
+  f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0, u2 = u0, u3 = u0;
+  for (int sl = 0; sl < splits; ++sl) {
+    const f32x4* q = src + sl * slab4;
+    u0 += q[0]; u1 += q[3L * C4]; u2 += q[6L * C4]; u3 += q[9L * C4];
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(dw) + (k * 9 + r * 3) * C4 + c4;
+  const f32x4 h = 0.5f * (u1 + u2);
+  dst[0] = u0 + h;
+  dst[C4] = 0.5f * (u1 - u2);
+  dst[2L * C4] = h + u3;
+}
+
+// the Winograd-domain weight gradient: 3x3 / stride 1 / pad 1, even Q, C % 4 == 0, square tiles whose width divides 3*C
+// NNL_WGRAD_WINO: 0 never, 2 wherever it is legal, 1 (default) where it MEASURED faster than the direct kernel
+// (tools/bench_conv.py --ab NNL_WGRAD_WINO=0,2 at 8 / 16 / 32 / 64 images and --net r50 --bs 16; profiles/r3_wwg_*.log):
+//   C = 128: +6 ... +21 % everywhere (6272 ... 32768 pairs);          C = 64: +5 / +11 % at 100352 / 131072 pairs, -11 / -26 % at
+//   50176 / 25088 (12 column tiles of 64 need ~100 splits of the minimum 256 rows: fixed cost per workgroup);
+//   C = 256: +19 % at 6272 pairs, +-0 at 8192, -30 % at 32768 (16 x 64 x 64 FPN level: the 4-group 128x128 variant it then takes
+//   spills 10 VGPRs).  The weight gradient is summed in a different order either way; both are bitwise reproducible run to run.
+bool wgrad_wino_ok(const nnl_conv_geom_t* g) {
+  const int mode = NNL_ENV_INT("NNL_WGRAD_WINO", 1);
+  if (mode == 0) return false;
+  if (g->R != 3 || g->S != 3 || g->stride != 1 || g->pad != 1 || g->Q % 2 != 0 || g->C % 64 != 0 || g->K % 4 != 0) return false;
+  const long pairs = (long)g->N * g->P * (g->Q / 2);
+  if (pairs < 1024 || !wgrad_v2_ok(2 * pairs * g->K, (long)g->N * g->H * g->W * g->C, pairs)) return false;
+  if (mode == 2) return true;
+  if (g->C == 64) return pairs >= 65536;
+  if (g->C == 128) return pairs >= 4096;
+  return pairs >= 4096 && pairs <= 16384;
+}
+
+WgradPlan plan_wgrad_wino(const nnl_conv_geom_t* g) {
+  return plan_wgrad(g->K, 12 * g->C, (long)g->N * g->P * (g->Q / 2), 3 * g->C);
+}
+
+int launch_wgrad_wino(const float* dy, const float* x, float* slabs, const nnl_conv_geom_t* g, const WgradPlan& pl, hipStream_t s) {
+  IgemmWgradParams q{};
+  const long pairs = (long)g->N * g->P * (g->Q / 2);
+  q.a = dy; q.b = x; q.y = slabs;
+  q.a_bytes = (unsigned)(2 * pairs * g->K * 4); q.b_bytes = (unsigned)((long)g->N * g->H * g->W * g->C * 4);
+  q.H = g->H; q.W = g->W; q.C = g->C; q.P = g->P; q.Q = g->Q / 2; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1;
+  q.Mc = g->K; q.Nc = 12 * g->C; q.Kp = (int)pairs;
+  q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
+  q.n_fast = 1;
+  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits);
+  auto lds_bytes = [](int bm, int bn, int bk, int kg) { return (size_t)kg * 2 * bk * (bm + bn) * sizeof(float); };
+#define NNL_WGRAD_WINO_LAUNCH(BM_, BN_, BK_, KG_)                                                                                \
+  do {                                                                                                                           \
+    const size_t lb = lds_bytes(BM_, BN_, BK_, KG_);                                                                             \
+    if (lb > 64 * 1024) {                                                                                                        \
+      static bool attr_set = false;                                                                                              \
+      if (!attr_set) {                                                                                                           \
+        NNL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, true, KG_, true>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));                                 \
+        attr_set = true;                                                                                                         \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, true, KG_, true>), grid, dim3(256 * KG_), lb, s, q);             \
+  } while (0)
+  if (pl.bm == 128) {
+    if (pl.kg == 4) NNL_WGRAD_WINO_LAUNCH(128, 128, 16, 4);
+    else if (pl.kg == 2) NNL_WGRAD_WINO_LAUNCH(128, 128, 16, 2);
+    else NNL_WGRAD_WINO_LAUNCH(128, 128, 16, 1);
+  } else if (pl.k_per_split % 32 == 0) {
+    if (pl.kg == 4) NNL_WGRAD_WINO_LAUNCH(64, 64, 32, 4);
+    else if (pl.kg == 2) NNL_WGRAD_WINO_LAUNCH(64, 64, 32, 2);
+    else NNL_WGRAD_WINO_LAUNCH(64, 64, 32, 1);
+  } else {
+    NNL_WGRAD_WINO_LAUNCH(64, 64, 16, 1);
+  }
+#undef NNL_WGRAD_WINO_LAUNCH
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
@@ -971,6 +1057,8 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
 
 extern "C" size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g) {
   if (!g || g->K <= 0 || g->C <= 0) return 0;
+  if (wgrad_wino_ok(g))                                     // the Winograd-domain slabs [splits][K][12*C] (always: dU is folded to dW from them)
+    return (size_t)plan_wgrad_wino(g).splits * g->K * 12 * g->C * sizeof(float);
   const WgradPlan pl = plan_wgrad(g->K, g->R * g->S * g->C, (long)g->N * g->P * g->Q);
   return pl.splits > 1 ? (size_t)pl.splits * g->K * g->R * g->S * g->C * sizeof(float) : 0;
 }
@@ -994,6 +1082,16 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
     return nnl_set_error(NNL_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
   p.y = pl.splits > 1 ? (float*)workspace : dw;
   NnlProfScope prof(NNL_PROF_CONV_WGRAD, s, 2.0 * p.Kp * (double)p.Mc * p.Nc);
+  if (wgrad_wino_ok(g)) {                                   // Winograd-domain weight gradient (igemm_wgrad.h, WINO) + the fold-back reduce
+    const WgradPlan wp = plan_wgrad_wino(g);
+    int st2 = launch_wgrad_wino(dy, x, (float*)workspace, g, wp, s);
+    if (st2) return st2;
+    const long n4 = (long)g->K * 3 * (g->C / 4);
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)nnl_cdiv(n4, 256L)), dim3(256), 0, s, (const float*)workspace, dw, n4,
+                       g->C / 4, wp.splits, (long)g->K * 12 * (g->C / 4));
+    NNL_CHECK_LAUNCH();
+    return NNL_OK;
+  }
   const long a_elems = p.Kp * g->K, b_elems = (long)g->N * g->H * g->W * g->C;
   if (wgrad_v2_ok(a_elems, b_elems, p.Kp)) {
     int st2 = launch_wgrad_v2(dy, x, p.y, a_elems, b_elems, g->H, g->W, g->C, g->P, g->Q, g->R, g->S, g->stride, g->pad, p.Mc,

@@ -19,13 +19,22 @@ struct IgemmWgradParams {
   int Mc, Nc, Kp;
   int splits, k_per_split, grid_m, grid_n;
   int n_fast;          // tile order inside a split: 1 = column tiles fastest (neighbours share the dy columns), 0 = row tiles fastest
+  // WINO instantiations (3x3 / stride 1 / pad 1, even Q): the reduction index runs over output PAIRS (n, p, j) — Kp = N*P*Q/2,
+  // Q below = pairs per line — and the columns over (position xi, filter row r, ci): Nc = 12*C, y = dU [Mc][4][3][C] (slabs);
+  // a column tile never straddles a position (3*C % BN == 0).  See the kernel.
 };
 
 // KG > 1 (round 3): a workgroup is KG GROUPS of 4 waves (256*KG threads); group g reduces the g-th quarter / half of the split's
 // pixel range into its own accumulators with its own LDS staging buffers, and the groups' accumulators are added through LDS in
 // group order (deterministic) before group 0 writes ONE slab.  Same waves per CU as KG co-resident 256-thread workgroups, but KG
 // times fewer split-K slabs written to and re-read from HBM (the 128x128 tile at KG = 4: 66 MB -> 17 MB per launch).
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int KG = 1>
+// WINO (round 3): the weight gradient of a 3x3 / stride 1 / pad 1 convolution in the Winograd F(2,3) domain of wino.hip — with
+//   y(2j) = M0 + M1 + M2, y(2j+1) = M1 - M2 + M3',  M_xi = sum V_xi U_xi:   dU_xi[co][r][ci] = sum over pairs of dM_xi[co] * V_xi(r)[ci],
+//   dM0 = dy(2j), dM1 = dy(2j) + dy(2j+1), dM2 = dy(2j) - dy(2j+1), dM3' = dy(2j+1);  V as in the forward (d0-d2, d1+d2, d2-d1, d3-d1).
+// Both transforms happen while the operand tiles are staged (two buffer loads and one add per element each); the reduction runs
+// over HALF as many rows against 12/9 as many columns: 1.5x fewer MFMA multiplies.  The slab reduce that follows folds dU back
+// to dW (dg0 = dU0 + (dU1 + dU2)/2, dg1 = (dU1 - dU2)/2, dg2 = (dU1 + dU2)/2 + dU3: wino_wgrad_finish_kernel, conv2d.hip).
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int KG = 1, bool WINO = false>
 __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 : 4)) void igemm_wgrad_kernel(const IgemmWgradParams p) {
   static_assert(WGM * WGN == 4, "4 waves per group");
   static_assert(KG == 1 || (size_t)KG * 2 * BK * (BM + BN) >= (size_t)BM * BN, "the staging LDS must hold one accumulator tile for the group reduction");
@@ -82,42 +91,55 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 
   const bool b_cok = b_col < p.Nc;
   const int btap = (b_cok ? b_col : 0) / p.C;
   const int bc = (b_cok ? b_col : 0) - btap * p.C;
-  const int br = btap / p.S, bs = btap - br * p.S;
+  const int br = WINO ? btap % 3 : btap / p.S, bs = WINO ? 0 : btap - br * p.S;
   const int PQ = p.P * p.Q;
-  const int dh = br - p.pad, dw = bs - p.pad;
+  // WINO: position xi of this column tile (tile-uniform), the two input columns (2*qq - 1 + wca / wcb) of V_xi and their sign,
+  // the two coefficients of dM_xi = ac0 * dy(2*qq) + ac1 * dy(2*qq + 1)
+  const int xi = WINO ? n0 / (3 * p.C) : 0;
+  const int wca = xi, wcb = xi < 2 ? 2 : 1;
+  const float bsgn = xi == 1 ? 1.f : -1.f;
+  const float ac0 = xi == 3 ? 0.f : 1.f, ac1 = xi == 0 ? 0.f : (xi == 2 ? -1.f : 1.f);
+  const int dh = br - p.pad, dw = WINO ? wca - 1 : bs - p.pad;
+  const int qstep = WINO ? 2 : p.stride;                                     // input columns per unit of qq
 
   f32x4 ra[PA], rb[PB];
+  f32x4 ra2[WINO ? PA : 1], rb2[WINO ? PB : 1];                              // WINO: the second pixel of each pair
   // Per-row gather state, advanced INCREMENTALLY by BK pixels per k tile (no division, multiplication or branch in the loop):
   // a pixel index k = (n, pp, qq) moves by BK = dn*P*Q + dp*Q + dq, with at most one carry out of qq and one out of pp; the
   // byte offset of its input pixel moves by a constant plus one constant per carry.  Row validity is two unsigned range
   // tests on (pp, qq) against per-thread bounds (the thread's tap (dh, dw) is fixed) and k < k_end.
   const int adv_n = BK / PQ, adv_r = BK - adv_n * PQ, adv_p = adv_r / p.Q, adv_q = adv_r - adv_p * p.Q;
-  const int step_px = p.stride * p.C * 4;                                    // bytes per unit of qq
+  const int step_px = qstep * p.C * 4;                                       // bytes per unit of qq
   const int step_row = p.stride * p.W * p.C * 4;                             // bytes per unit of pp
   const int off_adv = adv_n * p.H * p.W * p.C * 4 + adv_p * step_row + adv_q * step_px;
   const int off_qwrap = step_row - p.Q * step_px;                            // qq -= Q, pp += 1
   const int off_pwrap = p.H * p.W * p.C * 4 - p.P * step_row;                // pp -= P, n += 1
   // pp valid  <=>  0 <= pp*stride + dh < H  <=>  pp in [pp_lo, pp_hi)
-  const int pp_lo = dh < 0 ? (-dh + p.stride - 1) / p.stride : 0, qq_lo = dw < 0 ? (-dw + p.stride - 1) / p.stride : 0;
-  const int pp_hi = min(p.P, (p.H - dh + p.stride - 1) / p.stride), qq_hi = min(p.Q, (p.W - dw + p.stride - 1) / p.stride);
+  const int pp_lo = dh < 0 ? (-dh + p.stride - 1) / p.stride : 0, qq_lo = dw < 0 ? (-dw + qstep - 1) / qstep : 0;
+  const int pp_hi = min(p.P, (p.H - dh + p.stride - 1) / p.stride), qq_hi = min(p.Q, (p.W - dw + qstep - 1) / qstep);
   const unsigned pp_span = pp_hi > pp_lo ? (unsigned)(pp_hi - pp_lo) : 0u, qq_span = qq_hi > qq_lo ? (unsigned)(qq_hi - qq_lo) : 0u;
+  // WINO: the second column 2*qq - 1 + wcb of the pair, delta bytes from the first
+  const int dw2 = wcb - 1;
+  const int q2_lo = dw2 < 0 ? 1 : 0, q2_hi = min(p.Q, (p.W - dw2 + 1) / 2);
+  const unsigned q2_span = q2_hi > q2_lo ? (unsigned)(q2_hi - q2_lo) : 0u;
+  const int delta_b = (wcb - wca) * p.C * 4;
   int a_k[PA]; unsigned a_off[PA];
   int b_k[PB], b_pp[PB], b_qq[PB], b_off[PB];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     a_k[i] = k_begin + ra_row + i * RA;
-    a_off[i] = (unsigned)(a_k[i] * p.Mc + a_col) * 4u;
+    a_off[i] = WINO ? (unsigned)(2 * a_k[i] * p.Mc + a_col) * 4u : (unsigned)(a_k[i] * p.Mc + a_col) * 4u;     // WINO: pixel 2k (Q even)
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int k = k_begin + rb_row + i * RB;
     const int n = k / PQ, rem = k - n * PQ;
     b_k[i] = k; b_pp[i] = rem / p.Q; b_qq[i] = rem - b_pp[i] * p.Q;
-    b_off[i] = (((n * p.H + b_pp[i] * p.stride + dh) * p.W + b_qq[i] * p.stride + dw) * p.C + bc) * 4;
+    b_off[i] = (((n * p.H + b_pp[i] * p.stride + dh) * p.W + b_qq[i] * qstep + dw) * p.C + bc) * 4;
   }
   auto advance = [&]() {
 #pragma unroll
-    for (int i = 0; i < PA; ++i) { a_k[i] += BK; a_off[i] += (unsigned)(BK * p.Mc) * 4u; }
+    for (int i = 0; i < PA; ++i) { a_k[i] += BK; a_off[i] += (unsigned)((WINO ? 2 : 1) * BK * p.Mc) * 4u; }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       b_k[i] += BK;
@@ -130,6 +152,21 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 
     }
   };
   auto load_tile = [&]() {
+    if constexpr (WINO) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const unsigned o = (a_cok && a_k[i] < k_end) ? a_off[i] : 0xFFFFFFFFu;
+        ra[i] = buf_load4(ra_src, ac0 != 0.f ? o : 0xFFFFFFFFu, 0);                                   // (wave-uniform selects)
+        ra2[i] = buf_load4(ra_src, ac1 != 0.f ? o : 0xFFFFFFFFu, (unsigned)p.Mc * 4u);
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const bool okp = b_cok && b_k[i] < k_end && (unsigned)(b_pp[i] - pp_lo) < pp_span;
+        rb[i] = buf_load4(rb_src, (okp && (unsigned)(b_qq[i] - qq_lo) < qq_span) ? (unsigned)b_off[i] : 0xFFFFFFFFu, 0);
+        rb2[i] = buf_load4(rb_src, (okp && (unsigned)(b_qq[i] - q2_lo) < q2_span) ? (unsigned)(b_off[i] + delta_b) : 0xFFFFFFFFu, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, (a_cok && a_k[i] < k_end) ? a_off[i] : 0xFFFFFFFFu, 0);
 #pragma unroll
@@ -141,6 +178,23 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 
   auto store_tile = [&](int buf) {
     float* As = lds[buf];
     float* Bs = As + BK * BM;
+    if constexpr (WINO) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ac0 * ra[i][e] + ac1 * ra2[i][e];
+        *reinterpret_cast<f32x4*>(As + (ra_row + i * RA) * BM + ca * 4) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rb[i][e] + bsgn * rb2[i][e];
+        *reinterpret_cast<f32x4*>(Bs + (rb_row + i * RB) * BN + cb * 4) = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(As + (ra_row + i * RA) * BM + ca * 4) = ra[i];
 #pragma unroll
