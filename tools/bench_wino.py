@@ -55,9 +55,15 @@ def main():
             check(f(ptr(xin), ptr(filt), ptr(bias), ptr(add), ptr(out), ptr(ws), wsb, ptr(counters), counters.numel(),
                     ptr(part) if bn else None, ptr(piv) if bn else None, N, H, H, cc, kk, relu, flip, stream()))
 
-        os.environ['NNL_CONV_WINO'] = '0'; lib.nnl_reload_env()       # the references below: the DIRECT implicit-GEMM kernel
-        with torch.no_grad():
-            ref = ops.conv2d(x, w, b, 1, 1, relu=True).permute(0, 2, 3, 1).contiguous()
+        def direct(fn):                      # the references: the DIRECT implicit-GEMM kernel (NNL_CONV_WINO=0 around the call)
+            os.environ['NNL_CONV_WINO'] = '0'; lib.nnl_reload_env()
+            try:
+                with torch.no_grad():
+                    return fn()
+            finally:
+                os.environ['NNL_CONV_WINO'] = '1'; lib.nnl_reload_env()
+
+        ref = direct(lambda: ops.conv2d(x, w, b, 1, 1, relu=True).permute(0, 2, 3, 1).contiguous())
         flops = 2.0 * N * H * H * K * 9 * Cc
         out = {'layer': name, 'N': N, 'C': Cc, 'K': K, 'H': H, 'ws_MB': round(wsb / 2 ** 20, 1)}
         run()
@@ -65,8 +71,7 @@ def main():
         out['diff_vs_direct'] = (y - ref).abs().max().item()
         # addend + BatchNorm partials, no ReLU
         run(relu=0, add=addt, bn=True)
-        with torch.no_grad():
-            ref2 = ops.conv2d(x, w, b, 1, 1, relu=False).permute(0, 2, 3, 1) + addt
+        ref2 = direct(lambda: ops.conv2d(x, w, b, 1, 1, relu=False).permute(0, 2, 3, 1) + addt)
         out['diff_add'] = (y - ref2).abs().max().item()
         d = (ref2 - piv).reshape(-1, K).double()
         s1, s2 = part[:, :, 0].double().sum(0), part[:, :, 1].double().sum(0)
@@ -87,8 +92,7 @@ def main():
         t = timed(lambda: run())
         out['wino_us'] = round(t, 1)
         out['wino_tflops_algorithmic'] = round(flops / t / 1e6, 1)
-        with torch.no_grad():
-            td = timed(lambda: ops.conv2d(x, w, b, 1, 1, relu=True))
+        td = direct(lambda: timed(lambda: ops.conv2d(x, w, b, 1, 1, relu=True)))
         out['direct_us_incl_host'] = round(td, 1)
         r64 = torch.relu(torch.nn.functional.conv2d(x[:1].double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)).permute(0, 2, 3, 1)
         run()
