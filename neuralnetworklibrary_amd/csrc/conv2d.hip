@@ -543,6 +543,10 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     /
   const bool kg_tile = (pl.bm == 128 && pl.bn == 128) || (pl.bm == 64 && pl.bn == 64);
   if (kg_tile && e_kg != 1 && pl.splits >= 2) {
     int kg = (pl.bm == 128 && pl.splits >= 16) ? 4 : 1;
+    // Winograd-domain columns (square_bn_divides = 3 * C): the 4-group 128x128 WINO instantiation spills (two staged pixels per
+    // operand: 10 VGPRs over), and merged groups measured SLOWER there — RetinaNet FPN level 16 x 64 x 64, C = K = 256: 0.49 ms
+    // with one group per workgroup, 0.75 with two, 0.94 with four (direct kernel: 0.66)
+    if (square_bn_divides != 0 && pl.bm == 128) kg = 1;
     if (e_kg == 2 || e_kg == 4) kg = pl.splits >= e_kg ? e_kg : 1;
     if (kg > 1) {
       const long sp = nnl_cdiv(pl.splits, kg);
@@ -646,8 +650,9 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 // (tools/bench_conv.py --ab NNL_WGRAD_WINO=0,2 at 8 / 16 / 32 / 64 images and --net r50 --bs 16; profiles/r3_wwg_*.log):
 //   C = 128: +6 ... +21 % everywhere (6272 ... 32768 pairs);          C = 64: +5 / +11 % at 100352 / 131072 pairs, -11 / -26 % at
 //   50176 / 25088 (12 column tiles of 64 need ~100 splits of the minimum 256 rows: fixed cost per workgroup);
-//   C = 256: +19 % at 6272 pairs, +-0 at 8192, -30 % at 32768 (16 x 64 x 64 FPN level: the 4-group 128x128 variant it then takes
-//   spills 10 VGPRs).  The weight gradient is summed in a different order either way; both are bitwise reproducible run to run.
+//   C >= 256 (one wave group per workgroup: see plan_wgrad): +19 % at 6272 pairs (14 x 14 stage, 64 images), +35 ... +40 % on the
+//   RetinaNet levels (8192 / 32768 pairs: 0.181 -> 0.130 ms, 0.657 -> 0.488 ms), +23 % at C = 512 / 16 x 16.
+//   The weight gradient is summed in a different order either way; both are bitwise reproducible run to run.
 bool wgrad_wino_ok(const nnl_conv_geom_t* g) {
   const int mode = NNL_ENV_INT("NNL_WGRAD_WINO", 1);
   if (mode == 0) return false;
@@ -656,8 +661,7 @@ bool wgrad_wino_ok(const nnl_conv_geom_t* g) {
   if (pairs < 1024 || !wgrad_v2_ok(2 * pairs * g->K, (long)g->N * g->H * g->W * g->C, pairs)) return false;
   if (mode == 2) return true;
   if (g->C == 64) return pairs >= 65536;
-  if (g->C == 128) return pairs >= 4096;
-  return pairs >= 4096 && pairs <= 16384;
+  return pairs >= 2048;                                       // (16 x 16 x 16 levels, C = 256 / 512: 0.058 -> 0.047 ms, 0.181 -> 0.147 ms)
 }
 
 WgradPlan plan_wgrad_wino(const nnl_conv_geom_t* g) {
