@@ -629,20 +629,32 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
 // index order (bitwise reproducible), then dg0 = dU0 + (dU1 + dU2)/2, dg1 = (dU1 - dU2)/2, dg2 = (dU1 + dU2)/2 + dU3.
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, long n4,
                                                                  int C4, int splits, long slab4) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;                 // over (k, r, c4)
-  if (i >= n4) return;
-  const long c4 = i % C4, kr = i / C4, r = kr % 3, k = kr / 3;
-  const f32x4* src = reinterpret_cast<const f32x4*>(part) + (k * 12 + r) * C4 + c4;
+  // 256 threads = 32 (k, r, c4) items x 8 split lanes: lane l adds slabs l, l+8, ... IN THAT ORDER for the four positions, the eight
+  // partial sums meet in LDS in lane order (fixed order => bitwise reproducible); lane 0 folds the positions back and writes
+  __shared__ f32x4 red[8][32][4];
+  const int it = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const long i = (long)blockIdx.x * 32 + it;                           // over (k, r, c4)
   f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = u0, u2 = u0, u3 = u0;
-  for (int sl = 0; sl < splits; ++sl) {
-    const f32x4* q = src + sl * slab4;
-    u0 += q[0]; u1 += q[3L * C4]; u2 += q[6L * C4]; u3 += q[9L * C4];
+  long c4 = 0, r = 0, k = 0;
+  if (i < n4) {
+    c4 = i % C4; const long kr = i / C4; r = kr % 3; k = kr / 3;
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + (k * 12 + r) * C4 + c4;
+    for (int s = sl; s < splits; s += 8) {
+      const f32x4* q = src + s * slab4;
+      u0 += q[0]; u1 += q[3L * C4]; u2 += q[6L * C4]; u3 += q[9L * C4];
+    }
   }
-  f32x4* dst = reinterpret_cast<f32x4*>(dw) + (k * 9 + r * 3) * C4 + c4;
-  const f32x4 h = 0.5f * (u1 + u2);
-  dst[0] = u0 + h;
-  dst[C4] = 0.5f * (u1 - u2);
-  dst[2L * C4] = h + u3;
+  red[sl][it][0] = u0; red[sl][it][1] = u1; red[sl][it][2] = u2; red[sl][it][3] = u3;
+  __syncthreads();
+  if (sl == 0 && i < n4) {
+#pragma unroll
+    for (int l = 1; l < 8; ++l) { u0 += red[l][it][0]; u1 += red[l][it][1]; u2 += red[l][it][2]; u3 += red[l][it][3]; }
+    f32x4* dst = reinterpret_cast<f32x4*>(dw) + (k * 9 + r * 3) * C4 + c4;
+    const f32x4 h = 0.5f * (u1 + u2);
+    dst[0] = u0 + h;
+    dst[C4] = 0.5f * (u1 - u2);
+    dst[2L * C4] = h + u3;
+  }
 }
 
 // the Winograd-domain weight gradient: 3x3 / stride 1 / pad 1, even Q, C % 4 == 0, square tiles whose width divides 3*C
@@ -1091,7 +1103,7 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
     int st2 = launch_wgrad_wino(dy, x, (float*)workspace, g, wp, s);
     if (st2) return st2;
     const long n4 = (long)g->K * 3 * (g->C / 4);
-    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)nnl_cdiv(n4, 256L)), dim3(256), 0, s, (const float*)workspace, dw, n4,
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)nnl_cdiv(n4, 32L)), dim3(256), 0, s, (const float*)workspace, dw, n4,
                        g->C / 4, wp.splits, (long)g->K * 12 * (g->C / 4));
     NNL_CHECK_LAUNCH();
     return NNL_OK;
