@@ -500,6 +500,8 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     /
     const Cand& c = cands[ci];
     if (square_bn_divides != 0) {
       if (c.bm != c.bn || square_bn_divides % c.bn != 0 || (c.bm == 128 && Mc < 128)) continue;
+      const int f_w = NNL_ENV_INT("NNL_WGRAD_WINO_TILE", -1);          // A/B hook: 0 = 128x128, 3 = 64x64 (when legal)
+      if ((f_w == 0 || f_w == 3) && ci != f_w && !(f_w == 0 && (Mc < 128 || square_bn_divides % 128 != 0))) continue;
     } else if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
     const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
     const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
