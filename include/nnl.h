@@ -145,6 +145,27 @@ int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv
  *   bn_part / bn_pivot (both or neither): BatchNorm partial statistics as for nnl_conv2d_fwd, one per 64 output pairs.
  * nnl_debug_conv_plan_times: out[0] / out[1] = predicted launch time (us) of the direct / the Winograd kernel for that problem;
  *   returns 1 when the dispatcher would pick the Winograd kernel, else 0. */
+/* Prepared filters.  The transformed filter of a layer depends on its weights only, so a caller that knows all its layers can
+ * transform them in ONE launch per step instead of one per convolution call:
+ *   nnl_conv2d_wino_preferred(g, dgrad): 1 when nnl_conv2d_fwd (dgrad = 0) / nnl_conv2d_dgrad (dgrad = 1) would take the Winograd kernel
+ *     for geometry g (given the workspace of the size query), else 0;
+ *   nnl_wino_filter_multi: descriptor d transforms src [rows,3,3,ch] into dst [rows,4,3,ch]; flip = 0 with src = w[K,3,3,C]
+ *     (rows = K, ch = C) gives the FORWARD filter, flip = 1 with src = W^T[C,3,3,K] (rows = C, ch = K: nnl_conv2d_weight_transpose)
+ *     the DGRAD filter; block_desc[b] = descriptor served by block b, first_block = its first block, ceil(rows*3*ch / 256) blocks each;
+ *   nnl_conv2d_fwd_pre / nnl_conv2d_dgrad_pre: nnl_conv2d_fwd / nnl_conv2d_dgrad with `u` = that prepared filter (NULL: exactly the
+ *     plain entry points); u is used only when the Winograd kernel is taken and must then hold rows * 12 * ch floats. */
+typedef struct {
+  const float* src;
+  float* dst;
+  int32_t rows, ch, flip, first_block;
+} nnl_wino_desc_t;
+int nnl_conv2d_wino_preferred(const nnl_conv_geom_t* g, int dgrad);
+int nnl_wino_filter_multi(const nnl_wino_desc_t* desc, const int32_t* block_desc, int64_t n_blocks, void* stream);
+int nnl_conv2d_fwd_pre(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g, int relu,
+                       void* workspace, size_t workspace_bytes, int32_t* tile_counters, float* bn_partials, const float* bn_pivot,
+                       int32_t* bn_rows, const float* u, void* stream);
+int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
+                         void* workspace, size_t workspace_bytes, int32_t* tile_counters, const float* u, void* stream);
 size_t nnl_debug_conv_wino_workspace_bytes(int N, int H, int W, int C, int K);
 int nnl_debug_conv_wino_fwd(const float* x, const float* filt, const float* bias, const float* add, float* y, void* ws,
                             size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,

@@ -591,16 +591,25 @@ class Learner(object):
         opt.opt.zero_grad()
         if self.grad_sync is not None:
             self.grad_sync.begin(self._dp_weight)
-        y_pred = self.predict1minibatch(x_batch)
-        loss = self.loss_func(y_pred, y_batch)
-        early = loss.is_cuda and loss.numel() == 1 and not torch.cuda.is_current_stream_capturing()
-        if early:
-            if self._loss_host is None:
-                self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
-                self._loss_event = torch.cuda.Event()
-            self._loss_host.copy_(loss.detach().reshape(()).float(), non_blocking=True)
-            self._loss_event.record()
-        self._backward(loss)
+        on_gpu = default_device().type == 'cuda'
+        if on_gpu:
+            from .. import ops
+            ops.prepare_forward(self.model)              # the Winograd filters of all conv layers in one launch (ops.prepare_forward)
+        try:
+            y_pred = self.predict1minibatch(x_batch)
+            loss = self.loss_func(y_pred, y_batch)
+            early = loss.is_cuda and loss.numel() == 1 and not torch.cuda.is_current_stream_capturing()
+            if early:
+                if self._loss_host is None:
+                    self._loss_host = torch.empty((), dtype=torch.float32).pin_memory()
+                    self._loss_event = torch.cuda.Event()
+                self._loss_host.copy_(loss.detach().reshape(()).float(), non_blocking=True)
+                self._loss_event.record()
+            self._backward(loss)                         # (closes the prepared-filter window in its own `finally`)
+        except BaseException:
+            if on_gpu:
+                ops.finish_backward()                    # the window must not outlive a failed step: the next forward may follow a weight change
+            raise
         opt.step()
         if early:
             self._loss_event.synchronize()

@@ -865,9 +865,21 @@ extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
 
 extern "C" int64_t nnl_conv2d_tile_counters(void) { return kTileCounters; }
 
+extern "C" int nnl_conv2d_wino_preferred(const nnl_conv_geom_t* g, int dgrad) {
+  if (!g) return 0;
+  return dgrad ? (wino_preferred(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad) ? 1 : 0)
+               : (wino_preferred(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad) ? 1 : 0);
+}
+
 extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
                               int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, float* bn_partials,
                               const float* bn_pivot, int32_t* bn_rows, void* stream) {
+  return nnl_conv2d_fwd_pre(x, w, bias, y, g, relu, workspace, workspace_bytes, tile_counters, bn_partials, bn_pivot, bn_rows, nullptr, stream);
+}
+
+extern "C" int nnl_conv2d_fwd_pre(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
+                                  int relu, void* workspace, size_t workspace_bytes, int32_t* tile_counters, float* bn_partials,
+                                  const float* bn_pivot, int32_t* bn_rows, const float* u, void* stream) {
   if (bn_rows) *bn_rows = 0;
   int st = check_geom(g, "conv2d_fwd");
   if (st) return st;
@@ -889,6 +901,7 @@ extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias,
     wq.N = g->N; wq.H = g->H; wq.W = g->W; wq.Cin = g->C; wq.Nc = g->K; wq.relu = relu; wq.flip = 0;
     const bool stats = bn_partials && bn_pivot && bn_rows;
     wq.bn_part = stats ? bn_partials : nullptr; wq.bn_pivot = bn_pivot;
+    wq.u_pre = u;
     st = nnl_wino_launch(wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
     if (st == NNL_OK && stats) *bn_rows = nnl_wino_bn_rows(g->N, g->H, g->W);
     return st;
@@ -970,6 +983,11 @@ extern "C" int nnl_conv2d_weight_transpose_multi(const nnl_wt_desc_t* desc, cons
 
 extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
                                 void* workspace, size_t workspace_bytes, int32_t* tile_counters, void* stream) {
+  return nnl_conv2d_dgrad_pre(dy, wt, dx, g, addend, workspace, workspace_bytes, tile_counters, nullptr, stream);
+}
+
+extern "C" int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx, const nnl_conv_geom_t* g, const float* addend,
+                                    void* workspace, size_t workspace_bytes, int32_t* tile_counters, const float* u, void* stream) {
   int st = check_geom(g, "conv2d_dgrad");
   if (st) return st;
   NNL_CHECK_ARG(dy && wt && dx, "conv2d_dgrad: null pointer");
@@ -996,6 +1014,7 @@ extern "C" int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, con
     WinoProblem wq{};
     wq.in = dy; wq.filt = wt; wq.out = dx; wq.bias = nullptr; wq.add = addend;
     wq.N = g->N; wq.H = g->P; wq.W = g->Q; wq.Cin = g->K; wq.Nc = g->C; wq.relu = 0; wq.flip = 1;
+    wq.u_pre = u;
     return nnl_wino_launch(wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
   }
   if (taps_ok(a_elems, b_elems, g->K, g->R * g->S) && (g->stride == 1 || g->stride == 2)) {

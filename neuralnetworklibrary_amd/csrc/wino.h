@@ -9,6 +9,7 @@ struct WinoProblem {
   const float* in; const float* filt; float* out; const float* bias; const float* add;
   int N, H, W, Cin, Nc, relu, flip;
   float* bn_part; const float* bn_pivot;       // optional BatchNorm statistics of the output (see nnl_conv2d_fwd): one partial per 64-pair tile row
+  const float* u_pre;                          // optional: the transformed filter U [Nc][4][3][Cin] prepared by nnl_wino_filter_multi (skips the per-call transform)
 };
 
 bool nnl_wino_ok(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad);

@@ -57,6 +57,24 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
   o[9L * C] = g2;
 }
 
+// every filter of a model in ONE launch: block b transforms 256 (row, r, c) items of descriptor block_desc[b]
+__global__ void wino_filter_multi_kernel(const nnl_wino_desc_t* __restrict__ desc, const int32_t* __restrict__ block_desc) {
+  const nnl_wino_desc_t d = desc[block_desc[blockIdx.x]];
+  const long i = ((long)blockIdx.x - d.first_block) * 256 + threadIdx.x;
+  const long C = d.ch;
+  if (i >= (long)d.rows * 3 * C) return;
+  const long c = i % C, kr = i / C, r = kr % 3, k = kr / 3;
+  const long sr = d.flip ? 2 - r : r;
+  const float* src = d.src + ((k * 3 + sr) * 3) * C + c;
+  const float ga = src[0], gb = src[C], gc = src[2L * C];
+  const float g0 = d.flip ? gc : ga, g1 = gb, g2 = d.flip ? ga : gc;
+  float* o = d.dst + (k * 12 + r) * C + c;
+  o[0] = g0;
+  o[3L * C] = 0.5f * (g0 + g1 + g2);
+  o[6L * C] = 0.5f * (g0 - g1 + g2);
+  o[9L * C] = g2;
+}
+
 template <int BK>
 __global__ __launch_bounds__(256, 4) void wino_kernel(const WinoParams p) {
   constexpr int BM = 64, BN = 64, BKP = BK + 4, KC = BK / 4, RPP = 256 / KC, PA = BM / RPP, PB = BN / RPP;
@@ -423,11 +441,13 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
   const size_t u_floats = align4((size_t)q.Nc * 12 * q.Cin);
   if (ws == nullptr || ws_bytes < u_floats * sizeof(float)) return nnl_set_error(NNL_ERR_WORKSPACE, "wino: workspace too small");
   float* u = (float*)ws;
-  const long KC3 = (long)q.Nc * 3 * q.Cin;
-  hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)nnl_cdiv(KC3, 256L)), dim3(256), 0, s, q.filt, u, KC3, q.Cin, q.flip);
-  NNL_CHECK_LAUNCH();
+  if (q.u_pre == nullptr) {
+    const long KC3 = (long)q.Nc * 3 * q.Cin;
+    hipLaunchKernelGGL(wino_filter_kernel, dim3((unsigned)nnl_cdiv(KC3, 256L)), dim3(256), 0, s, q.filt, u, KC3, q.Cin, q.flip);
+    NNL_CHECK_LAUNCH();
+  }
   WinoParams p{};
-  p.a = q.in; p.b = u; p.y = q.out; p.bias = q.bias; p.add = q.add;
+  p.a = q.in; p.b = q.u_pre ? q.u_pre : u; p.y = q.out; p.bias = q.bias; p.add = q.add;
   p.a_bytes = (unsigned)((long)q.N * q.H * q.W * q.Cin * 4); p.b_bytes = (unsigned)((long)q.Nc * 12 * q.Cin * 4);
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.W2 = (q.W + 1) / 2; p.M2 = (int)M2; p.Nc = q.Nc; p.relu = q.relu;
   p.grid_m = (int)nnl_cdiv(M2, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
@@ -446,6 +466,13 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
   }
   if (pl.bk == 32) hipLaunchKernelGGL(wino_kernel<32>, dim3(grid), dim3(256), 0, s, p);
   else hipLaunchKernelGGL(wino_kernel<16>, dim3(grid), dim3(256), 0, s, p);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_wino_filter_multi(const nnl_wino_desc_t* desc, const int32_t* block_desc, int64_t n_blocks, void* stream) {
+  NNL_CHECK_ARG(desc && block_desc && n_blocks > 0 && n_blocks < (1LL << 31), "wino_filter_multi: bad arguments");
+  hipLaunchKernelGGL(wino_filter_multi_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, desc, block_desc);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

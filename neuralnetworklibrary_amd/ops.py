@@ -193,6 +193,80 @@ def _pad_c4(t_nhwc):
 _WT_ACTIVE = {}       # weight data_ptr -> W^T tensor [C,R,S,K]; valid ONLY between prepare_backward() and finish_backward()
 
 
+# Prepared Winograd filters (include/nnl.h: nnl_wino_filter_multi).  The transformed filter of a 3x3 / stride 1 / pad 1 layer depends
+# on its weights only; transforming it inside every convolution call costs one extra launch per call (58 per ResNet-34 step).
+# `prepare_forward(model)` (Learner, before the forward of a training step) and `prepare_backward(model)` transform the filters of all
+# layers that took the Winograd kernel at their LAST call (`_WINO_PREF`) in one launch each; the convolutions pick them up by weight
+# address.  The window closes in finish_backward() (Learner: in a `finally`), before the optimizer touches the weights.
+_WINO_U_FWD, _WINO_U_BWD = {}, {}     # weight data_ptr -> U [K,4,3,C] (forward) / U' [C,4,3,K] (dgrad)
+_WINO_PREF = {}                       # weight data_ptr -> [forward took the Winograd kernel, dgrad did] at the last call
+
+
+class _WinoBatch:
+    "persistent U buffers + device descriptor tables for nnl_wino_filter_multi: items = [(key_ptr, src tensor [rows,3,3,ch], flip)]"
+
+    def __init__(self, items):
+        import numpy as np
+        dev = items[0][1].device
+        self.key = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t, _ in items)
+        total = sum(t.shape[0] * 12 * t.shape[3] for _, t, _ in items)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        desc = np.zeros(len(items), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rows', '<i4'), ('ch', '<i4'), ('flip', '<i4'), ('first', '<i4')]))
+        block_desc, self.views, off, first = [], {}, 0, 0
+        for i, (k, t, flip) in enumerate(items):
+            rows, ch = t.shape[0], t.shape[3]
+            u = self.flat[off:off + rows * 12 * ch]
+            off += rows * 12 * ch
+            nb = (rows * 3 * ch + 255) // 256
+            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first)
+            block_desc += [i] * nb
+            first += nb
+            self.views[k] = u
+        self.n_blocks = first
+        self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+        self.block_desc = torch.tensor(block_desc, dtype=torch.int32, device=dev)
+
+    def run(self):
+        check(lib.nnl_wino_filter_multi(ptr(self.desc), ptr(self.block_desc), self.n_blocks, stream()))
+
+
+def _conv_mods(model):
+    mods = getattr(model, '_nnl_conv_mods', None)
+    if mods is None:                # the module walk costs ~0.1 ms per step on a host-bound model: done once.  A conv added
+        mods = [m for m in model.modules() if getattr(m, 'nnl_hip_conv', False)]     # later transforms its own filter (slower, correct)
+        object.__setattr__(model, '_nnl_conv_mods', mods)
+    return mods
+
+
+def _run_wino_batch(model, attr, items, out):
+    if not items:
+        return
+    key = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t, _ in items)
+    batch = getattr(model, attr, None)
+    if batch is None or batch.key != key:
+        if torch.cuda.is_current_stream_capturing():
+            return                                      # (buffers are built during eager steps)
+        batch = _WinoBatch(items)
+        object.__setattr__(model, attr, batch)
+    batch.run()
+    out.update(batch.views)
+
+
+def prepare_forward(model):
+    """Call right before the forward of a TRAINING step (Learner does): the Winograd filters of every HipConv2d whose last forward
+    took the Winograd kernel, in one launch; valid until finish_backward()."""
+    _WINO_U_FWD.clear()
+    if os.environ.get('NNL_WINO_PREPARE', '1') == '0':
+        return
+    items = []
+    for m in _conv_mods(model):
+        w = m.weight
+        if (w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.dtype == torch.float32
+                and w.is_contiguous(memory_format=torch.channels_last) and _WINO_PREF.get(w.data_ptr(), (0, 0))[0]):
+            items.append((w.data_ptr(), w.permute(0, 2, 3, 1), 0))          # KRSC view of the same memory
+    _run_wino_batch(model, '_nnl_wino_fwd_batch', items, _WINO_U_FWD)
+
+
 class _WtBatch:
     "persistent W^T buffers + device descriptor tables for the conv filters of one model (nnl_conv2d_weight_transpose_multi)"
 
@@ -225,10 +299,7 @@ def prepare_backward(model):
     """Call right before `loss.backward()` (Learner does): transposes the filters of every HipConv2d of `model` in ONE launch
     (one small launch per layer otherwise) and exposes them to the convolutions' backward until finish_backward().  The
     window is deliberately that short: a filter modified later can never meet a stale transpose."""
-    mods = getattr(model, '_nnl_conv_mods', None)
-    if mods is None:                # the module walk costs ~0.1 ms per step on a host-bound model: done once.  A conv added
-        mods = [m for m in model.modules() if getattr(m, 'nnl_hip_conv', False)]     # later transposes its own filter (slower, correct)
-        object.__setattr__(model, '_nnl_conv_mods', mods)
+    mods = _conv_mods(model)
     ws = [m.weight for m in mods
           if m.weight.is_cuda and m.weight.dim() == 4 and m.weight.shape[1] % 4 == 0
           and m.weight.shape[0] % 4 == 0 and m.weight.dtype == torch.float32
@@ -245,10 +316,29 @@ def prepare_backward(model):
     batch.run()
     _WT_ACTIVE.clear()
     _WT_ACTIVE.update(batch.views)
+    # the dgrad Winograd filters U' [C,4,3,K] of the layers whose last dgrad took the Winograd kernel, from the transposes above
+    _WINO_U_BWD.clear()
+    if os.environ.get('NNL_WINO_PREPARE', '1') != '0':
+        items = [(w.data_ptr(), batch.views[w.data_ptr()], 1) for w in ws
+                 if w.shape[2] == 3 and w.shape[3] == 3 and _WINO_PREF.get(w.data_ptr(), (0, 0))[1]]
+        _run_wino_batch(model, '_nnl_wino_bwd_batch', items, _WINO_U_BWD)
 
 
 def finish_backward():
+    "closes the window of everything prepare_forward / prepare_backward exposed (the optimizer is about to change the weights)"
     _WT_ACTIVE.clear()
+    _WINO_U_FWD.clear()
+    _WINO_U_BWD.clear()
+
+
+def _wino_pref(key_ptr, which, g):
+    "does nnl_conv2d_fwd (which = 0) / nnl_conv2d_dgrad (1) take the Winograd kernel for g?  Remembered per weight for the next step's batch"
+    pref = int(lib.nnl_conv2d_wino_preferred(g, which)) if (g.R == 3 and g.S == 3 and g.stride == 1) else 0
+    if pref or key_ptr in _WINO_PREF:
+        if len(_WINO_PREF) > 8192:
+            _WINO_PREF.clear()
+        _WINO_PREF.setdefault(key_ptr, [0, 0])[which] = pref
+    return pref
 
 
 # Gradient buffers whose rows are ALREADY padded with zeros to the GEMM granularity (the softmax-CE backward at V % 16 != 0, the
@@ -340,8 +430,11 @@ class _Conv2d(torch.autograd.Function):
         part, rows = None, _lib.i32(0)
         if bn_pivot is not None:                                  # BatchNorm statistics from the conv epilogue (include/nnl.h)
             part = torch.empty(((N * g.P * g.Q + 63) // 64) * K * 2, dtype=torch.float32, device=x.device)
-        check(lib.nnl_conv2d_fwd(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
-                                 ptr(part), ptr(bn_pivot), ctypes.byref(rows) if part is not None else None, stream()))
+        u = _WINO_U_FWD.get(wn.data_ptr()) if _wino_pref(wn.data_ptr(), 0, g) else None        # the filter prepared for this step, if any
+        if u is not None and u.numel() != K * 12 * C:
+            u = None
+        check(lib.nnl_conv2d_fwd_pre(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
+                                     ptr(part), ptr(bn_pivot), ctypes.byref(rows) if part is not None else None, ptr(u), stream()))
         if part is None or rows.value == 0:
             part = torch.empty(0, dtype=torch.float32, device=x.device)
         else:
@@ -410,8 +503,11 @@ class _Conv2d(torch.autograd.Function):
             # stride 2: every output-parity class of a 3x3 / pad 1 filter has a tap, so every dx pixel passes through the epilogue
             fuse = shortcut is not None and g.K % 16 == 0 and shortcut.numel() == dxn.numel() \
                 and (g.stride == 1 or (g.stride == 2 and g.R == 3 and g.S == 3 and g.pad == 1))
-            check(lib.nnl_conv2d_dgrad(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
-                                       ptr(_tile_counters(dyn.device) if wsb else None), stream()))
+            u = _WINO_U_BWD.get(wn.data_ptr()) if (_wino_pref(wn.data_ptr(), 1, g) and g.K == K) else None
+            if u is not None and u.numel() != g.C * 12 * g.K:
+                u = None
+            check(lib.nnl_conv2d_dgrad_pre(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
+                                           ptr(_tile_counters(dyn.device) if wsb else None), ptr(u), stream()))
             if shortcut is not None and not fuse:
                 dxn += shortcut.view_as(dxn)
             give = ctx.give_slot

@@ -295,3 +295,44 @@ def test_wgrad_winograd_domain(case, monkeypatch):
     sc = ref.abs().max().item()
     assert_close(dw_w, dw_d, rtol=1e-5, atol=2e-6 * sc, msg='dw Winograd vs direct')
     assert_close(dw_w, ref, rtol=1e-4, atol=1e-5 * sc, msg='dw Winograd vs torch')
+
+
+def test_prepared_winograd_filters_match_per_call_transform(monkeypatch):
+    """ops.prepare_forward / prepare_backward transform the Winograd filters of all layers in one launch each (nnl_wino_filter_multi)
+    for the layers that took the Winograd kernel at their last call; the convolutions then run nnl_conv2d_fwd_pre / _dgrad_pre on
+    them.  Same bits as the per-call transform (NNL_WINO_PREPARE=0), and the window closes with finish_backward()."""
+    from neuralnetworklibrary_amd import ops
+    from neuralnetworklibrary_amd._lib import lib
+    import torch.nn as nn
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
+    monkeypatch.setenv('NNL_CONV_WINO', '2'); lib.nnl_reload_env()        # the Winograd kernel wherever it applies (small test shapes)
+    torch.manual_seed(3)
+    net = nn.Sequential(HipConv2d(64, 128, 3, padding=1), nn.ReLU(), HipConv2d(128, 64, 3, padding=1)).to(DEV)
+    x = torch.randn(4, 64, 20, 18, device=DEV)
+    dy = torch.randn(4, 64, 20, 18, device=DEV)
+
+    def step(prepare):
+        monkeypatch.setenv('NNL_WINO_PREPARE', '1' if prepare else '0')
+        xg = x.clone().requires_grad_(True)
+        for p in net.parameters():
+            p.grad = None
+        ops.prepare_forward(net)
+        n_fwd = len(ops._WINO_U_FWD)
+        y = net(xg)
+        ops.prepare_backward(net)
+        n_bwd = len(ops._WINO_U_BWD)
+        try:
+            y.backward(dy)
+        finally:
+            ops.finish_backward()
+        assert not ops._WINO_U_FWD and not ops._WINO_U_BWD and not ops._WT_ACTIVE, 'the prepared-filter window stayed open'
+        return y.detach(), xg.grad, [p.grad.clone() for p in net.parameters()], n_fwd, n_bwd
+
+    ref = step(False)                       # also teaches _WINO_PREF which layers take the Winograd kernel
+    assert ref[3] == 0 and ref[4] == 0
+    got = step(True)
+    assert got[3] == 2 and got[4] == 2, 'prepared filters were not built for both layers (fwd %d, dgrad %d)' % (got[3], got[4])
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    for a, b in zip(got[2], ref[2]):
+        assert torch.equal(a, b)
+    monkeypatch.delenv('NNL_CONV_WINO'); lib.nnl_reload_env()
