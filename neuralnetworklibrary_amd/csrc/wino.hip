@@ -454,8 +454,9 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
   p.bn_part = q.bn_part; p.bn_pivot = q.bn_pivot;
   const long T = (long)p.grid_m * p.grid_n;
   WPlan pl = wino_plan(M2, q.Nc, q.Cin);
-  if (pl.on && (tile_counters == nullptr || T > n_counters || ws_bytes < (u_floats + pl.main_floats + pl.tail_floats) * sizeof(float)))
-    pl.on = 0;                                       // split tiles are finished in-kernel only
+  if (pl.on && (tile_counters == nullptr || T > n_counters || ws_bytes < (u_floats + pl.main_floats + pl.tail_floats) * sizeof(float) ||
+                pl.main_floats * sizeof(float) >= (1UL << 31) || pl.tail_floats * sizeof(float) >= (1UL << 31)))
+    pl.on = 0;                                       // split tiles are finished in-kernel only; a slab region is one 2 GB buffer resource
   unsigned grid = (unsigned)T;
   if (pl.on) {
     p.bal = 1; p.main_ks = pl.main_ks; p.n_main_tiles = pl.n_main_tiles; p.tail_slices = pl.tail_slices; p.tail_row0 = pl.tail_row0;
