@@ -1,61 +1,41 @@
-"""Time ops.linear forward + backward for the structured-data MLP's GEMM shapes as they are (C = 203 / 1000 / 500: not multiples
-of 16) and zero-padded to the next multiple of 16 / 32 — how much does the first-generation kernel cost these layers?
-python tools/bench_linear.py"""
-import json
+"""Times ops.linear forward / backward of one shape (default: the AWD-LSTM decoder 4480 x 400 -> 47343) with the library's own
+per-kind HIP-event profile.  Usage (GPU box): python tools/bench_linear.py [M K N]"""
+import os
 import sys
+
 import torch
-sys.path.insert(0, '.')
-from neuralnetworklibrary_amd import ops
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neuralnetworklibrary_amd import _lib, ops  # noqa: E402
+
+M, K, N = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (4480, 400, 47343)
+x = torch.randn(M, K, device='cuda', requires_grad=True)
+w = torch.randn(N, K, device='cuda', requires_grad=True)
+b = torch.zeros(N, device='cuda', requires_grad=True)
+dy = torch.randn(M, N, device='cuda')
 
 
-def timed(fn, n=50, warm=10):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n * 1e3     # us
+def step():
+    x.grad = w.grad = b.grad = None
+    y = ops.linear(x, w, b)
+    y.backward(dy)
 
 
-def main():
-    dev = torch.device('cuda:0')
-    out = []
-    for M, C, K in [(1024, 203, 1000), (1024, 204, 1000), (1024, 208, 1000), (1024, 224, 1000), (1024, 1000, 500), (1024, 1008, 500), (1024, 1024, 500),
-                    (1024, 500, 1), (1024, 512, 1), (1024, 512, 4)]:
-        x = torch.randn(M, C, device=dev, requires_grad=True)
-        w = torch.randn(K, C, device=dev, requires_grad=True)
-        b = torch.randn(K, device=dev, requires_grad=True)
-        dy = torch.randn(M, K, device=dev)
-
-        def fwd():
-            return ops.linear(x, w, b, relu=True)
-
-        def fwd_bwd():
-            y = ops.linear(x, w, b, relu=True)
-            y.backward(dy)
-            x.grad = w.grad = b.grad = None
-
-        with torch.no_grad():
-            tf = timed(fwd)
-        tfb = timed(fwd_bwd)
-        # the same under a captured graph (host launch cost excluded)
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(3):
-                fwd_bwd()
-        torch.cuda.current_stream().wait_stream(s)
-        with torch.cuda.graph(g):
-            fwd_bwd()
-        tg = timed(g.replay)
-        out.append({'M': M, 'C': C, 'K': K, 'fwd_us': round(tf, 1), 'fwd_bwd_us': round(tfb, 1), 'fwd_bwd_graph_us': round(tg, 1)})
-        print(json.dumps(out[-1]), flush=True)
-
-
-if __name__ == '__main__':
-    main()
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+_lib.prof_enable(True)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+n = 10
+for _ in range(n):
+    step()
+e1.record()
+torch.cuda.synchronize()
+_lib.prof_enable(False)
+prof = _lib.prof_collect()
+flop = 2.0 * M * K * N
+print('linear %d x %d -> %d: %.3f ms per fwd+bwd (%.1f TF/s over 3 GEMMs)' % (M, K, N, e0.elapsed_time(e1) / n, 3 * flop / (e0.elapsed_time(e1) / n * 1e-3) / 1e12))
+for k, v in prof.items():
+    if v['launches']:
+        print('  %-12s %7.3f ms/step  %s' % (k, v['ms'] / n, ('%.1f TF/s' % (v['work'] / (v['ms'] * 1e-3) / 1e12)) if k.startswith('conv') else ''))
