@@ -82,6 +82,7 @@ static bool taps_pf2(int bk, const IgemmTapsParams&) {
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
   p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
+  p.epi4 = NNL_ENV_INT("NNL_IGEMM_EPI4", 1);
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
   p.cls_tiles = p.grid_m * p.grid_n;
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 
 int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counters, hipStream_t s) {
   p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
+  p.epi4 = NNL_ENV_INT("NNL_IGEMM_EPI4", 1);
   p.grid_m = (int)nnl_cdiv(p.M, pl.bm);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
   const int T = p.grid_m * p.grid_n;

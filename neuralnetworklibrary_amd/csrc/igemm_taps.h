@@ -63,6 +63,7 @@ struct IgemmTapsParams {
   // reduce kernel sums (deterministic).  tail rows start at tail_row0 (n_main_tiles is a multiple of grid_n).
   int bal, main_ks, n_main_tiles, tail_slices, tail_row0;
   LstmEpi lstm;                        // EPI != 0 instantiations only
+  int epi4;                            // 1: row-major float4 epilogue of the unsplit 64x64 tile (dense outputs; NNL_IGEMM_EPI4)
   int variant;                         // 1: PIPE instantiation of the 64x64 kernel (A/B: tools/bench_conv.py --ab NNL_IGEMM_VARIANT=0,1)
   float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
   float* tail_out; long tail_slab_stride;      // tail_slices > 1: slabs [tail_slices][M - tail_row0][Nc]
@@ -672,6 +673,55 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)
       }
     }
     return;
+  }
+  if constexpr (EPI == 0 && BM == 64 && BN == 64) {
+    if (p.epi4 && dense_out && !p.add_up2 && !partial && p.Nc % 4 == 0) {
+      // ---- row-major float4 epilogue: the accumulator tile goes through LDS (free: the k loop ended with a barrier) and every
+      // thread finishes four float4 pieces of output rows — 16 lanes cover a 256-B row segment per store instead of 32 lanes
+      // writing 128 B of two rows each with 4-byte stores (the 1x1 convolutions of the ResNet-50 body write 4x what they read:
+      // their time IS this epilogue), and the addend / bias / BatchNorm pivot come in as float4 too
+      constexpr int LDT = 68;
+      float* tl = &lds[0][0];                              // 64 x 68 floats
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tl[(wm * 32 + (e & 3) + 8 * (e >> 2) + row_h) * LDT + wn * 32 + col_l] = acc[0][0][e];
+      __syncthreads();
+      float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = n0 + (idx4 & 15) * 4;
+        const int row = m0 + rl;
+        if (row >= p.M || c4 >= p.Nc) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(tl + rl * LDT + (idx4 & 15) * 4);
+        const long o = (long)row * p.Nc + c4;
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
+        if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
+        if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        else if (p.relu == 2) { v[0] = nnl_sigmoid(v[0]); v[1] = nnl_sigmoid(v[1]); v[2] = nnl_sigmoid(v[2]); v[3] = nnl_sigmoid(v[3]); }
+        *reinterpret_cast<f32x4*>(p.y + o) = v;
+        if (p.bn_part) {
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(p.bn_pivot + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; fs1[e] += d; fs2[e] += d * d; }
+        }
+      }
+      if (p.bn_part) {                              // thread t owns columns (t & 15)*4..+3 of rows t>>4, +16, +32, +48
+        __syncthreads();
+        float* red = &lds[0][0];                      // [16 row lanes][64 cols][2]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 0] = fs1[e];
+          red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 1] = fs2[e];
+        }
+        __syncthreads();
+        if (tid < 64 && n0 + tid < p.Nc) {
+          float a = 0.f, b = 0.f;
+          for (int r = 0; r < 16; ++r) { a += red[(r * 64 + tid) * 2]; b += red[(r * 64 + tid) * 2 + 1]; }
+          p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 0] = a;
+          p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 1] = b;
+        }
+      }
+      return;
+    }
   }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {

@@ -39,6 +39,7 @@ struct WinoParams {
   float* tail_out; long tail_slab_stride;
   int* tile_counters;
   float* bn_part; const float* bn_pivot;
+  int epi4;            // 1: row-major float4 epilogue of the unsplit tiles (NNL_WINO_EPI4, default)
 };
 
 // filt [Nc][3][3][C] -> U [Nc][4][3][C]; flip: read filt[.][2-r][2-s][.] (the dgrad filter)
@@ -307,6 +308,57 @@ __global__ __launch_bounds__(256, 4) void wino_kernel(const WinoParams p) {
     }
     return;
   }
+  if (p.epi4 && p.Nc % 4 == 0) {
+    // ---- row-major float4 epilogue (as igemm_taps_kernel's): the two accumulator tiles go through LDS one after the other (the k
+    // loop ended with a barrier) and every thread finishes four float4 pieces of output rows per half: 16 lanes write a 256-B row
+    // segment per store; addend / bias / BatchNorm pivot come in as float4 ----
+    constexpr int LDT = 68;
+    float* tl = &lds[0][0];                                // 64 x 68 floats (BK 16: 5120 available)
+    float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tl[(wm * 32 + (e & 3) + 8 * (e >> 2) + row_h) * LDT + wn * 32 + col_l] = h ? y1[e] : y0[e];
+      __syncthreads();
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = n0 + (idx4 & 15) * 4;
+        const int row = m0 + rl;
+        if (row >= p.M2 || c4 >= p.Nc) continue;
+        const int line = row / p.W2, j = row - line * p.W2;
+        if (2 * j + h >= p.W) continue;                    // the missing second output of an odd line
+        f32x4 v = *reinterpret_cast<const f32x4*>(tl + rl * LDT + (idx4 & 15) * 4);
+        const long o = ((long)line * p.W + 2 * j + h) * p.Nc + c4;
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
+        if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
+        if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(p.y + o) = v;
+        if (p.bn_part) {
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(p.bn_pivot + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; fs1[e] += d; fs2[e] += d * d; }
+        }
+      }
+    }
+    if (p.bn_part) {                                       // thread t owns columns (t & 15)*4..+3 of rows t>>4, +16, +32, +48 (both halves)
+      __syncthreads();
+      float* red = &lds[0][0];                             // [16 row lanes][64 cols][2]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 0] = fs1[e];
+        red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 1] = fs2[e];
+      }
+      __syncthreads();
+      if (tid < 64 && n0 + tid < p.Nc) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 16; ++r) { a += red[(r * 64 + tid) * 2]; b += red[(r * 64 + tid) * 2 + 1]; }
+        p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 0] = a;
+        p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 1] = b;
+      }
+    }
+    return;
+  }
   const int col = n0 + wn * 32 + col_l;
   const bool cok = col < p.Nc;
   const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
@@ -452,6 +504,7 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.W2 = (q.W + 1) / 2; p.M2 = (int)M2; p.Nc = q.Nc; p.relu = q.relu;
   p.grid_m = (int)nnl_cdiv(M2, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
   p.bn_part = q.bn_part; p.bn_pivot = q.bn_pivot;
+  p.epi4 = NNL_ENV_INT("NNL_WINO_EPI4", 1);
   const long T = (long)p.grid_m * p.grid_n;
   WPlan pl = wino_plan(M2, q.Nc, q.Cin);
   if (pl.on && (tile_counters == nullptr || T > n_counters || ws_bytes < (u_floats + pl.main_floats + pl.tail_floats) * sizeof(float) ||
