@@ -51,6 +51,8 @@ SIGNATURES = {
     'nnl_conv2d_dgrad_pre': (C.c_int, [c_p, c_p, c_p, C.POINTER(ConvGeom), c_p, c_p, sz, c_p, c_p, c_p]),
     'nnl_debug_conv_wino_workspace_bytes': (sz, [C.c_int] * 5),
     'nnl_debug_conv_wino_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
+    'nnl_debug_conv_wino2_workspace_bytes': (sz, [C.c_int] * 5),
+    'nnl_debug_conv_wino2_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
     'nnl_debug_conv_plan_times': (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_double)]),
     'nnl_conv2d_fwd': (C.c_int, [c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), C.c_int, c_p, sz, c_p, c_p, c_p, C.POINTER(i32), c_p]),
     'nnl_conv2d_weight_transpose': (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p]),

@@ -336,3 +336,60 @@ def test_prepared_winograd_filters_match_per_call_transform(monkeypatch):
     for a, b in zip(got[2], ref[2]):
         assert torch.equal(a, b)
     monkeypatch.delenv('NNL_CONV_WINO'); lib.nnl_reload_env()
+
+
+@pytest.mark.parametrize('case', [(2, 64, 12, 10, 64, None), (3, 32, 9, 7, 36, None), (4, 128, 14, 14, 128, (2, 4)), (1, 16, 2, 2, 8, None),
+                                  (2, 64, 17, 33, 96, (1, 3))], ids=str)
+def test_winograd_2d_debug_entry(case, monkeypatch):
+    """The experimental 2-D F(2x2, 3x3) kernel (csrc/wino2.hip, reachable through nnl_debug_conv_wino2_fwd only — not dispatched;
+    profiles/README.md has the measurements): forward with bias / addend / ReLU / BatchNorm partial sums and the flipped dgrad
+    filter, odd heights and widths, plain grid and forced k-slicing (in-kernel slab fix-up), against torch CPU fp32."""
+    from neuralnetworklibrary_amd._lib import lib, ptr, stream, check
+    N, C, H, W, K, forced = case
+    if forced:
+        monkeypatch.setenv('NNL_WINO_PLAN_KS', str(forced[0])); monkeypatch.setenv('NNL_WINO_PLAN_S', str(forced[1]))
+    lib.nnl_reload_env()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(K, 3, 3, C, generator=g) / (C * 9) ** 0.5
+    b = torch.randn(K, generator=g)
+    add = torch.randn(N, H, W, K, generator=g)
+    piv = torch.randn(K, generator=g) * 0.1
+    dy = torch.randn(N, H, W, K, generator=g)
+    counters = torch.zeros(4096, dtype=torch.int32, device=DEV)
+    wsb = max(lib.nnl_debug_conv_wino2_workspace_bytes(N, H, W, C, K), lib.nnl_debug_conv_wino2_workspace_bytes(N, H, W, K, C))
+    ws = torch.empty(wsb // 4 + 4, device=DEV)
+    rows = (N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64
+    part = torch.zeros(rows, K, 2, device=DEV)
+    xd, wd, bd, addd, pivd = x.to(DEV), w.to(DEV), b.to(DEV), add.to(DEV), piv.to(DEV)
+    y = torch.empty(N, H, W, K, device=DEV)
+
+    def run(xin, filt, bias, addt, out, cc, kk, relu, flip, bn):
+        check(lib.nnl_debug_conv_wino2_fwd(ptr(xin), ptr(filt), ptr(bias), ptr(addt), ptr(out), ptr(ws), wsb, ptr(counters), counters.numel(),
+                                           ptr(part) if bn else None, ptr(pivd) if bn else None, N, H, W, cc, kk, relu, flip, stream()))
+
+    ref_lin = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
+    sc = ref_lin.abs().max().item()
+    run(xd, wd, bd, None, y, C, K, 1, 0, False)
+    assert_close(y, torch.relu(ref_lin), rtol=1e-4, atol=1e-5 * sc, msg='2-D Winograd forward + bias + ReLU')
+    y1 = y.clone()
+    run(xd, wd, bd, None, y, C, K, 1, 0, False)
+    assert torch.equal(y, y1), 'bitwise reproducible'
+    run(xd, wd, bd, addd, y, C, K, 0, 0, True)
+    ref2 = ref_lin + add
+    assert_close(y, ref2, rtol=1e-4, atol=1e-5 * sc, msg='2-D Winograd forward + addend')
+    d = (ref2 - piv).reshape(-1, K).double()
+    s1, s2 = part[:, :, 0].double().sum(0).cpu(), part[:, :, 1].double().sum(0).cpu()
+    assert ((s1 - d.sum(0)).abs().max() / d.abs().sum(0).max()).item() < 1e-5
+    assert ((s2 - (d * d).sum(0)).abs().max() / (d * d).sum(0).max()).item() < 1e-5
+    assert int(counters.abs().sum()) == 0, 'tile counters back to zero'
+    if K % 16 == 0:                                           # the dgrad direction: dy has K channels
+        wt = w.permute(3, 1, 2, 0).contiguous()               # [C][R][S][K]
+        dx = torch.empty(N, H, W, C, device=DEV)
+        run(dy.to(DEV), wt.to(DEV), None, None, dx, K, C, 0, 1, False)
+        refdx = torch.nn.grad.conv2d_input((N, C, H, W), w.permute(0, 3, 1, 2).contiguous(), dy.permute(0, 3, 1, 2).contiguous(),
+                                           padding=1).permute(0, 2, 3, 1)
+        assert_close(dx, refdx, rtol=1e-4, atol=1e-5 * refdx.abs().max().item(), msg='2-D Winograd dgrad filter')
+    if forced:
+        monkeypatch.delenv('NNL_WINO_PLAN_KS'); monkeypatch.delenv('NNL_WINO_PLAN_S')
+    lib.nnl_reload_env()

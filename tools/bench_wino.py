@@ -30,12 +30,13 @@ def timed(fn, n=30, warm=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bs', type=int, default=64)
+    ap.add_argument('--two-d', action='store_true', help='the 2-D F(2x2,3x3) kernel (csrc/wino2.hip)')
     args = ap.parse_args()
-    f = lib.nnl_debug_conv_wino_fwd                    # (signatures: neuralnetworklibrary_amd/_lib.py)
-    fw = lib.nnl_debug_conv_wino_workspace_bytes
+    f = lib.nnl_debug_conv_wino2_fwd if args.two_d else lib.nnl_debug_conv_wino_fwd      # (signatures: neuralnetworklibrary_amd/_lib.py)
+    fw = lib.nnl_debug_conv_wino2_workspace_bytes if args.two_d else lib.nnl_debug_conv_wino_workspace_bytes
     dev = torch.device('cuda:0')
     counters = torch.zeros(1 << 16, dtype=torch.int32, device=dev)
-    for name, Cc, K, H in [('l1', 64, 64, 56), ('l2', 128, 128, 28), ('l3', 256, 256, 14), ('l4', 512, 512, 7), ('odd', 64, 128, 9)]:
+    for name, Cc, K, H in [('l1', 64, 64, 56), ('l2', 128, 128, 28), ('l3', 256, 256, 14), ('l4', 512, 512, 7), ('odd', 64, 128, 9), ('fpn', 256, 256, 32)]:
         N = args.bs
         g = torch.Generator(device=dev).manual_seed(1)
         x = torch.randn(N, Cc, H, H, device=dev, generator=g).contiguous(memory_format=torch.channels_last)
@@ -48,7 +49,7 @@ def main():
         y = torch.empty(N, H, H, K, device=dev)
         wsb = fw(N, H, H, Cc, K)
         ws = torch.empty(max(wsb // 4, 1), device=dev)
-        nrows = (N * H * ((H + 1) // 2) + 63) // 64
+        nrows = (N * ((H + 1) // 2 if args.two_d else H) * ((H + 1) // 2) + 63) // 64
         part = torch.zeros(nrows, K, 2, device=dev)
 
         def run(relu=1, add=None, bn=False, flip=0, filt=wn, bias=b, xin=xn, out=y, cc=Cc, kk=K):
