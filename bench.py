@@ -732,7 +732,7 @@ def worker(args):
     last_loss = wl.loss
     n_prof = min(args.steps, 10)
     prof = profile_kinds(wl, n_prof)
-    roofline = mfma_roofline(prof, n_prof, kernel='igemm_taps_kernel / wino_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: '
+    roofline = mfma_roofline(prof, n_prof, kernel='igemm_taps_kernel / wino_kernel / wino2_kernel / igemm_wgrad_kernel (fp32 MFMA implicit-GEMM conv2d + linear: '
                                                   'fwd, dgrad, wgrad; incl. their slab reduces and filter transforms)')
     roofline['note'] = ('achieved = ALGORITHMIC convolution flop (2 N P Q K R S C per pass, SURVEY.md 8d) / measured time: the 3x3 stride-1 '
                         'forward / dgrad launches run a fused Winograd F(2,3) kernel that issues 1.5x fewer MFMA multiplies than that count')

@@ -825,19 +825,39 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
 // images, profiles/r3_wino_*.log) the Winograd iteration costs 1.18x (BK 16) / 1.08x (BK 32) the direct one (two A loads and an add per
 // staged element, single accumulator chains: folded into nnl_wino_plan_time_us), both launches carry ~6 us the model does not see, and the filter transform adds a launch (3 us)
 // plus 21 * Cin * Nc * 4 bytes of traffic.  A 3 % margin keeps coin-flip cases on the direct kernel.
-static bool wino_preferred(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
-  if (!nnl_wino_ok(N, H, W, Cin, Nc, R, S, stride, pad)) return false;
-  if (NNL_ENV_INT("NNL_CONV_WINO", 1) == 2) return true;
-  const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
-  const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
-  return t_w < 0.97 * t_d;
+// Returns 0 (direct kernel), 1 (1-D F(2,3), wino.hip) or 2 (2-D F(2x2,3x3), wino2.hip).  The 2-D kernel issues 2.25x fewer multiplies
+// but works on a quarter of the direct kernel's tiles with four-pixel slabs and five loads per k step: it MEASURED faster than the
+// 1-D one from ~500 quad tiles up (profiles/r3_wino2d_probe.log, r3_wino2d_sizes.log: -9 ... -20 % at 512 ... 2048 tiles, +5 ... +25 %
+// below 400), so that is the rule (NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal).
+static int wino_mode(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
+  if (!nnl_wino_ok(N, H, W, Cin, Nc, R, S, stride, pad)) return 0;
+  const int e = NNL_ENV_INT("NNL_CONV_WINO", 1);
+  const bool two_ok = nnl_wino2_ok(N, H, W, Cin, Nc, R, S, stride, pad);
+  if (e == 3) return two_ok ? 2 : 1;
+  if (e != 2) {
+    const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
+    const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
+    if (!(t_w < 0.97 * t_d)) return 0;
+  } else {
+    return 1;
+  }
+  const long quad_tiles = nnl_cdiv((long)N * ((H + 1) / 2) * ((W + 1) / 2), 64L) * nnl_cdiv((long)Nc, 64L);
+  if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 500)) return 2;
+  return 1;
+}
+static size_t wino_mode_workspace(int mode, int N, int H, int W, int Cin, int Nc) {
+  return mode == 2 ? nnl_wino2_workspace_bytes(N, H, W, Cin, Nc) : nnl_wino_workspace_bytes(N, H, W, Cin, Nc);
+}
+static int wino_mode_launch(int mode, const WinoProblem& q, void* ws, size_t ws_bytes, int* counters, long n_counters, hipStream_t s) {
+  return mode == 2 ? nnl_wino2_launch(q, ws, ws_bytes, counters, n_counters, s) : nnl_wino_launch(q, ws, ws_bytes, counters, n_counters, s);
 }
 
-// debug / tuning: the two planners' predicted launch times (us) for a 3x3 / stride 1 / pad 1 problem: out[0] direct, out[1] Winograd
+// debug / tuning: the planners' predicted launch times (us) for a 3x3 / stride 1 / pad 1 problem: out[0] direct, out[1] Winograd 1-D, out[2] 2-D
 extern "C" int nnl_debug_conv_plan_times(int N, int H, int W, int Cin, int Nc, double* out) {
   out[0] = plan_balance((long)N * H * W, Nc, Cin, 9).t_us;
   out[1] = nnl_wino_plan_time_us(N, H, W, Cin, Nc);
-  return wino_preferred(N, H, W, Cin, Nc, 3, 3, 1, 1) ? 1 : 0;
+  out[2] = nnl_wino2_plan_time_us(N, H, W, Cin, Nc);
+  return wino_mode(N, H, W, Cin, Nc, 3, 3, 1, 1);
 }
 
 // (the larger of the direct kernel's slabs and the Winograd path's transformed filter + slabs: either may run, see wino.h)
@@ -846,8 +866,8 @@ extern "C" size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g) {
   const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
   if (!taps_ok(a_elems, b_elems, g->C, g->R * g->S)) return 0;
   size_t b = balance_workspace_bytes((long)g->N * g->P * g->Q, g->K, g->C, g->R * g->S);
-  if (wino_preferred(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad)) {
-    const size_t wb = nnl_wino_workspace_bytes(g->N, g->H, g->W, g->C, g->K);
+  if (const int wm = wino_mode(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad)) {
+    const size_t wb = wino_mode_workspace(wm, g->N, g->H, g->W, g->C, g->K);
     if (wb > b) b = wb;
   }
   return b;
@@ -858,8 +878,8 @@ extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
   const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
   if (!taps_ok(a_elems, b_elems, g->K, g->R * g->S)) return 0;
   size_t b = balance_workspace_bytes((long)g->N * g->H * g->W, g->C, g->K, g->R * g->S);
-  if (wino_preferred(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad)) {
-    const size_t wb = nnl_wino_workspace_bytes(g->N, g->P, g->Q, g->K, g->C);
+  if (const int wm = wino_mode(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad)) {
+    const size_t wb = wino_mode_workspace(wm, g->N, g->P, g->Q, g->K, g->C);
     if (wb > b) b = wb;
   }
   return b;
@@ -869,8 +889,8 @@ extern "C" int64_t nnl_conv2d_tile_counters(void) { return kTileCounters; }
 
 extern "C" int nnl_conv2d_wino_preferred(const nnl_conv_geom_t* g, int dgrad) {
   if (!g) return 0;
-  return dgrad ? (wino_preferred(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad) ? 1 : 0)
-               : (wino_preferred(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad) ? 1 : 0);
+  return dgrad ? wino_mode(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad)
+               : wino_mode(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad);
 }
 
 extern "C" int nnl_conv2d_fwd(const float* x, const float* w, const float* bias, float* y, const nnl_conv_geom_t* g,
@@ -895,17 +915,17 @@ extern "C" int nnl_conv2d_fwd_pre(const float* x, const float* w, const float* b
   p.M = g->N * g->P * g->Q; p.Nc = g->K; p.Kg = g->R * g->S * g->C; p.relu = relu;
   NnlProfScope prof(NNL_PROF_CONV_FWD, s, 2.0 * p.M * (double)p.Nc * p.Kg);
   const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
-  if (relu != 2 && workspace != nullptr && wino_preferred(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad) &&
-      workspace_bytes >= nnl_wino_workspace_bytes(g->N, g->H, g->W, g->C, g->K)) {
-    // 3x3 / stride 1 / pad 1: fused 1-D Winograd F(2,3) (wino.hip) — 1.5x fewer MFMA k-steps per output
+  const int wmode = (relu != 2 && workspace != nullptr) ? wino_mode(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad) : 0;
+  if (wmode && workspace_bytes >= wino_mode_workspace(wmode, g->N, g->H, g->W, g->C, g->K)) {
+    // 3x3 / stride 1 / pad 1: fused Winograd — 1-D F(2,3) (wino.hip, 1.5x fewer MFMA k-steps per output) or 2-D F(2x2,3x3) (wino2.hip, 2.25x)
     WinoProblem wq{};
     wq.in = x; wq.filt = w; wq.out = y; wq.bias = bias; wq.add = nullptr;
     wq.N = g->N; wq.H = g->H; wq.W = g->W; wq.Cin = g->C; wq.Nc = g->K; wq.relu = relu; wq.flip = 0;
     const bool stats = bn_partials && bn_pivot && bn_rows;
     wq.bn_part = stats ? bn_partials : nullptr; wq.bn_pivot = bn_pivot;
     wq.u_pre = u;
-    st = nnl_wino_launch(wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
-    if (st == NNL_OK && stats) *bn_rows = nnl_wino_bn_rows(g->N, g->H, g->W);
+    st = wino_mode_launch(wmode, wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
+    if (st == NNL_OK && stats) *bn_rows = wmode == 2 ? nnl_wino2_bn_rows(g->N, g->H, g->W) : nnl_wino_bn_rows(g->N, g->H, g->W);
     return st;
   }
   if (taps_ok(a_elems, b_elems, g->C, g->R * g->S)) {
@@ -1010,14 +1030,14 @@ extern "C" int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx,
   p.M = g->N * g->H * g->W; p.Nc = g->C; p.Kg = g->R * g->S * g->K; p.relu = 0;
   NnlProfScope prof(NNL_PROF_CONV_DGRAD, s, 2.0 * g->N * (double)g->P * g->Q * g->K * g->R * g->S * g->C);
   const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
-  if (workspace != nullptr && wino_preferred(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad) &&
-      workspace_bytes >= nnl_wino_workspace_bytes(g->N, g->P, g->Q, g->K, g->C)) {
+  const int wmode = workspace != nullptr ? wino_mode(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad) : 0;
+  if (wmode && workspace_bytes >= wino_mode_workspace(wmode, g->N, g->P, g->Q, g->K, g->C)) {
     // stride-1 dgrad of a 3x3 / pad 1 filter = the same convolution over dy with the flipped, transposed filter (wino.hip)
     WinoProblem wq{};
     wq.in = dy; wq.filt = wt; wq.out = dx; wq.bias = nullptr; wq.add = addend;
     wq.N = g->N; wq.H = g->P; wq.W = g->Q; wq.Cin = g->K; wq.Nc = g->C; wq.relu = 0; wq.flip = 1;
     wq.u_pre = u;
-    return nnl_wino_launch(wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
+    return wino_mode_launch(wmode, wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
   }
   if (taps_ok(a_elems, b_elems, g->K, g->R * g->S) && (g->stride == 1 || g->stride == 2)) {
     IgemmTapsParams q{};

@@ -16,6 +16,7 @@
 // the slabs in slice order: bitwise reproducible) carries over with k = (position, filter row, channel block).
 // Measured (tools/bench_wino.py, 64 images): see profiles/README.md.
 #include "wino.h"
+#include "wino_filter.h"
 #include "igemm_taps.h"
 
 namespace {
@@ -58,11 +59,15 @@ __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restric
   o[9L * C] = g2;
 }
 
-// every filter of a model in ONE launch: block b transforms 256 (row, r, c) items of descriptor block_desc[b]
+// every filter of a model in ONE launch: block b transforms 256 (row, r, c) items — 2-D layout: (row, c) items — of descriptor block_desc[b]
 __global__ void wino_filter_multi_kernel(const nnl_wino_desc_t* __restrict__ desc, const int32_t* __restrict__ block_desc) {
   const nnl_wino_desc_t d = desc[block_desc[blockIdx.x]];
   const long i = ((long)blockIdx.x - d.first_block) * 256 + threadIdx.x;
   const long C = d.ch;
+  if (d.two_d) {                                     // U [rows][16][ch] of the 2-D kernel: one (row, channel) item per thread
+    if (i < (long)d.rows * C) wino2_filter_item(d.src + (i / C) * 9 * C + i % C, d.dst + (i / C) * 16 * C + i % C, C, d.flip);
+    return;
+  }
   if (i >= (long)d.rows * 3 * C) return;
   const long c = i % C, kr = i / C, r = kr % 3, k = kr / 3;
   const long sr = d.flip ? 2 - r : r;

@@ -10,6 +10,7 @@
 // steps per output instead of 9 (2.25x fewer; 1-D: 6).  All positions accumulate into one tile that is folded into the four
 // output tiles with the position's coefficients when the position's channel loop ends.  Tile = 64 quads x 64 channels, 4 waves.
 #include "wino.h"
+#include "wino_filter.h"
 #include "igemm_taps.h"
 
 namespace {
@@ -34,30 +35,6 @@ struct Wino2Params {
   int* tile_counters;
   float* bn_part; const float* bn_pivot;
 };
-
-// filt [Nc][3][3][C] -> U [Nc][16][C]; flip: read filt[.][2-r][2-s][.] (the dgrad filter)
-__device__ __forceinline__ void wino2_filter_item(const float* __restrict__ src, float* __restrict__ dst, long C, int flip) {
-  float g[3][3];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int s = 0; s < 3; ++s) g[r][s] = src[((flip ? 2 - r : r) * 3 + (flip ? 2 - s : s)) * C];
-  float t[4][3];                                      // G g
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    t[0][s] = g[0][s];
-    t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
-    t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
-    t[3][s] = g[2][s];
-  }
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi) {
-    dst[(xi * 4 + 0) * C] = t[xi][0];
-    dst[(xi * 4 + 1) * C] = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]);
-    dst[(xi * 4 + 2) * C] = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]);
-    dst[(xi * 4 + 3) * C] = t[xi][2];
-  }
-}
 
 __global__ void wino2_filter_kernel(const float* __restrict__ w, float* __restrict__ u, long KC, int C, int flip) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over (k, c)

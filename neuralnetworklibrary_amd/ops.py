@@ -203,22 +203,25 @@ _WINO_PREF = {}                       # weight data_ptr -> [forward took the Win
 
 
 class _WinoBatch:
-    "persistent U buffers + device descriptor tables for nnl_wino_filter_multi: items = [(key_ptr, src tensor [rows,3,3,ch], flip)]"
+    """persistent U buffers + device descriptor tables for nnl_wino_filter_multi: items = [(key_ptr, src tensor [rows,3,3,ch], flip, mode)],
+    mode as nnl_conv2d_wino_preferred: 1 -> U [rows,12,ch] (1-D kernel), 2 -> U [rows,16,ch] (2-D kernel)"""
 
     def __init__(self, items):
         import numpy as np
         dev = items[0][1].device
-        self.key = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t, _ in items)
-        total = sum(t.shape[0] * 12 * t.shape[3] for _, t, _ in items)
+        self.key = _wino_batch_key(items)
+        total = sum(t.shape[0] * (16 if mode == 2 else 12) * t.shape[3] for _, t, _, mode in items)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        desc = np.zeros(len(items), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rows', '<i4'), ('ch', '<i4'), ('flip', '<i4'), ('first', '<i4')]))
+        desc = np.zeros(len(items), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rows', '<i4'), ('ch', '<i4'), ('flip', '<i4'), ('first', '<i4'),
+                                                    ('two_d', '<i4'), ('reserved', '<i4')]))
         block_desc, self.views, off, first = [], {}, 0, 0
-        for i, (k, t, flip) in enumerate(items):
+        for i, (k, t, flip, mode) in enumerate(items):
             rows, ch = t.shape[0], t.shape[3]
-            u = self.flat[off:off + rows * 12 * ch]
-            off += rows * 12 * ch
-            nb = (rows * 3 * ch + 255) // 256
-            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first)
+            n = rows * (16 if mode == 2 else 12) * ch
+            u = self.flat[off:off + n]
+            off += n
+            nb = (rows * ch + 255) // 256 if mode == 2 else (rows * 3 * ch + 255) // 256
+            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first, 1 if mode == 2 else 0, 0)
             block_desc += [i] * nb
             first += nb
             self.views[k] = u
@@ -228,6 +231,10 @@ class _WinoBatch:
 
     def run(self):
         check(lib.nnl_wino_filter_multi(ptr(self.desc), ptr(self.block_desc), self.n_blocks, stream()))
+
+
+def _wino_batch_key(items):
+    return tuple((k, t.data_ptr(), tuple(t.shape), mode) for k, t, _, mode in items)
 
 
 def _conv_mods(model):
@@ -241,7 +248,7 @@ def _conv_mods(model):
 def _run_wino_batch(model, attr, items, out):
     if not items:
         return
-    key = tuple((k, t.data_ptr(), tuple(t.shape)) for k, t, _ in items)
+    key = _wino_batch_key(items)
     batch = getattr(model, attr, None)
     if batch is None or batch.key != key:
         if torch.cuda.is_current_stream_capturing():
@@ -261,9 +268,10 @@ def prepare_forward(model):
     items = []
     for m in _conv_mods(model):
         w = m.weight
-        if (w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.dtype == torch.float32
-                and w.is_contiguous(memory_format=torch.channels_last) and _WINO_PREF.get(w.data_ptr(), (0, 0))[0]):
-            items.append((w.data_ptr(), w.permute(0, 2, 3, 1), 0))          # KRSC view of the same memory
+        mode = _WINO_PREF.get(w.data_ptr(), (0, 0))[0]
+        if (mode and w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.dtype == torch.float32
+                and w.is_contiguous(memory_format=torch.channels_last)):
+            items.append((w.data_ptr(), w.permute(0, 2, 3, 1), 0, mode))    # KRSC view of the same memory
     _run_wino_batch(model, '_nnl_wino_fwd_batch', items, _WINO_U_FWD)
 
 
@@ -319,7 +327,7 @@ def prepare_backward(model):
     # the dgrad Winograd filters U' [C,4,3,K] of the layers whose last dgrad took the Winograd kernel, from the transposes above
     _WINO_U_BWD.clear()
     if os.environ.get('NNL_WINO_PREPARE', '1') != '0':
-        items = [(w.data_ptr(), batch.views[w.data_ptr()], 1) for w in ws
+        items = [(w.data_ptr(), batch.views[w.data_ptr()], 1, _WINO_PREF[w.data_ptr()][1]) for w in ws
                  if w.shape[2] == 3 and w.shape[3] == 3 and _WINO_PREF.get(w.data_ptr(), (0, 0))[1]]
         _run_wino_batch(model, '_nnl_wino_bwd_batch', items, _WINO_U_BWD)
 
@@ -332,7 +340,9 @@ def finish_backward():
 
 
 def _wino_pref(key_ptr, which, g):
-    "does nnl_conv2d_fwd (which = 0) / nnl_conv2d_dgrad (1) take the Winograd kernel for g?  Remembered per weight for the next step's batch"
+    """which kernel nnl_conv2d_fwd (which = 0) / nnl_conv2d_dgrad (1) takes for g: 0 direct, 1 Winograd 1-D, 2 Winograd 2-D.  Remembered
+    per weight for the next step's batch (a weight shared between geometries keeps the mode of its LAST call; calls whose mode
+    differs transform their own filter: the prepared buffer is only handed over when its size is that of the mode's layout)"""
     pref = int(lib.nnl_conv2d_wino_preferred(g, which)) if (g.R == 3 and g.S == 3 and g.stride == 1) else 0
     if pref or key_ptr in _WINO_PREF:
         if len(_WINO_PREF) > 8192:
@@ -430,8 +440,9 @@ class _Conv2d(torch.autograd.Function):
         part, rows = None, _lib.i32(0)
         if bn_pivot is not None:                                  # BatchNorm statistics from the conv epilogue (include/nnl.h)
             part = torch.empty(((N * g.P * g.Q + 63) // 64) * K * 2, dtype=torch.float32, device=x.device)
-        u = _WINO_U_FWD.get(wn.data_ptr()) if _wino_pref(wn.data_ptr(), 0, g) else None        # the filter prepared for this step, if any
-        if u is not None and u.numel() != K * 12 * C:
+        wmode = _wino_pref(wn.data_ptr(), 0, g)
+        u = _WINO_U_FWD.get(wn.data_ptr()) if wmode else None   # the filter prepared for this step, if any — in THIS call's layout
+        if u is not None and u.numel() != K * (16 if wmode == 2 else 12) * C:
             u = None
         check(lib.nnl_conv2d_fwd_pre(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
                                      ptr(part), ptr(bn_pivot), ctypes.byref(rows) if part is not None else None, ptr(u), stream()))
@@ -503,8 +514,9 @@ class _Conv2d(torch.autograd.Function):
             # stride 2: every output-parity class of a 3x3 / pad 1 filter has a tap, so every dx pixel passes through the epilogue
             fuse = shortcut is not None and g.K % 16 == 0 and shortcut.numel() == dxn.numel() \
                 and (g.stride == 1 or (g.stride == 2 and g.R == 3 and g.S == 3 and g.pad == 1))
-            u = _WINO_U_BWD.get(wn.data_ptr()) if (_wino_pref(wn.data_ptr(), 1, g) and g.K == K) else None
-            if u is not None and u.numel() != g.C * 12 * g.K:
+            wmode = _wino_pref(wn.data_ptr(), 1, g)
+            u = _WINO_U_BWD.get(wn.data_ptr()) if (wmode and g.K == K) else None
+            if u is not None and u.numel() != g.C * (16 if wmode == 2 else 12) * g.K:
                 u = None
             check(lib.nnl_conv2d_dgrad_pre(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
                                            ptr(_tile_counters(dyn.device) if wsb else None), ptr(u), stream()))

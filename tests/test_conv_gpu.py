@@ -130,16 +130,17 @@ BAL_CASES = [
 ]
 
 
-@pytest.mark.parametrize('kernel', ['direct', 'winograd'])
+@pytest.mark.parametrize('kernel', ['direct', 'winograd', 'winograd2d'])
 @pytest.mark.parametrize('case', BAL_CASES, ids=[str(c) for c in BAL_CASES])
 def test_conv2d_balanced_schedule(case, kernel, monkeypatch):
     """kernel: the direct implicit-GEMM kernel (NNL_CONV_WINO=0; its schedule switch is NNL_IGEMM_BALANCE) and the fused Winograd
-    F(2,3) kernel that serves these 3x3 / stride 1 cases by default (wino.hip; NNL_WINO_BALANCE) — the same schedule, the same checks."""
+    F(2,3) kernel that serves these 3x3 / stride 1 cases by default (wino.hip; NNL_WINO_BALANCE), or its 2-D F(2x2,3x3) sibling (wino2.hip,
+    forced with NNL_CONV_WINO=3) — the same schedule, the same checks."""
     from neuralnetworklibrary_amd import ops
     from neuralnetworklibrary_amd._lib import lib
     N, C, H, K, R, stride, pad, has_bias, relu = case
     BAL = 'NNL_IGEMM_BALANCE' if kernel == 'direct' else 'NNL_WINO_BALANCE'
-    monkeypatch.setenv('NNL_CONV_WINO', '0' if kernel == 'direct' else '2'); lib.nnl_reload_env()    # 2: wherever it applies
+    monkeypatch.setenv('NNL_CONV_WINO', {'direct': '0', 'winograd': '2', 'winograd2d': '3'}[kernel]); lib.nnl_reload_env()    # 2 / 3: wherever it applies
     g = torch.Generator().manual_seed(7)
     x = torch.randn(N, C, H, H, generator=g)
     w = torch.randn(K, C, R, R, generator=g) / (C * R * R) ** 0.5
@@ -297,7 +298,8 @@ def test_wgrad_winograd_domain(case, monkeypatch):
     assert_close(dw_w, ref, rtol=1e-4, atol=1e-5 * sc, msg='dw Winograd vs torch')
 
 
-def test_prepared_winograd_filters_match_per_call_transform(monkeypatch):
+@pytest.mark.parametrize('mode', ['2', '3'], ids=['winograd', 'winograd2d'])
+def test_prepared_winograd_filters_match_per_call_transform(mode, monkeypatch):
     """ops.prepare_forward / prepare_backward transform the Winograd filters of all layers in one launch each (nnl_wino_filter_multi)
     for the layers that took the Winograd kernel at their last call; the convolutions then run nnl_conv2d_fwd_pre / _dgrad_pre on
     them.  Same bits as the per-call transform (NNL_WINO_PREPARE=0), and the window closes with finish_backward()."""
@@ -305,7 +307,7 @@ def test_prepared_winograd_filters_match_per_call_transform(monkeypatch):
     from neuralnetworklibrary_amd._lib import lib
     import torch.nn as nn
     from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
-    monkeypatch.setenv('NNL_CONV_WINO', '2'); lib.nnl_reload_env()        # the Winograd kernel wherever it applies (small test shapes)
+    monkeypatch.setenv('NNL_CONV_WINO', mode); lib.nnl_reload_env()       # the 1-D / 2-D Winograd kernel wherever it applies (small test shapes)
     torch.manual_seed(3)
     net = nn.Sequential(HipConv2d(64, 128, 3, padding=1), nn.ReLU(), HipConv2d(128, 64, 3, padding=1)).to(DEV)
     x = torch.randn(4, 64, 20, 18, device=DEV)
@@ -341,8 +343,8 @@ def test_prepared_winograd_filters_match_per_call_transform(monkeypatch):
 @pytest.mark.parametrize('case', [(2, 64, 12, 10, 64, None), (3, 32, 9, 7, 36, None), (4, 128, 14, 14, 128, (2, 4)), (1, 16, 2, 2, 8, None),
                                   (2, 64, 17, 33, 96, (1, 3))], ids=str)
 def test_winograd_2d_debug_entry(case, monkeypatch):
-    """The experimental 2-D F(2x2, 3x3) kernel (csrc/wino2.hip, reachable through nnl_debug_conv_wino2_fwd only — not dispatched;
-    profiles/README.md has the measurements): forward with bias / addend / ReLU / BatchNorm partial sums and the flipped dgrad
+    """The 2-D F(2x2, 3x3) kernel (csrc/wino2.hip) through its debug entry nnl_debug_conv_wino2_fwd (the dispatcher takes it from ~500
+    quad tiles up; profiles/README.md has the measurements): forward with bias / addend / ReLU / BatchNorm partial sums and the flipped dgrad
     filter, odd heights and widths, plain grid and forced k-slicing (in-kernel slab fix-up), against torch CPU fp32."""
     from neuralnetworklibrary_amd._lib import lib, ptr, stream, check
     N, C, H, W, K, forced = case

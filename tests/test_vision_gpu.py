@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from conftest import assert_close, load_golden
 from oracle import synth
@@ -90,6 +91,12 @@ def test_resnet34_full_baseline_size_forward_backward_vs_oracle():
     rounding noise) plus north_star's 1e-3.  ReLU makes the gradient discontinuous — a few dozen of the ~1e8 activations sit
     within rounding of zero and get the opposite gate in any two fp32 evaluations — so two correct fp32 implementations differ by
     more than 1e-3 on the early layers; the fp64 run shows that both sit equally far from the truth instead of waiving it.
+    The HEAD has the same discontinuity with a tight bound: its gradients see one ReLU layer (32 768 pre-activations, two of them
+    within 1e-4 of zero in fp64 for this batch) and the fp32 CPU run happens to flip none.  When a head tensor misses the bound, the
+    test looks for head gates that differ between the product's features and fp64, requires each such pre-activation to be zero
+    within north_star's tolerance (|p| <= 3 |p_cpu32 - p_f64|_max + 1e-3 |p_f64|_max), and re-adjudicates the head tensors against the
+    fp64 head evaluated WITH those gates — the same function up to a gate no fp32 run can determine (tools/wino2_head_flip_probe.py:
+    sample 1, feature 247, -1.6e-5 in fp64; the direct / 1-D Winograd builds land on the fp64 side, the 2-D one 2e-5 further).
     Exercises the balanced schedule, BK 16 / 32 tiles, split-K wgrad, the shortcut-gradient fusion, the BN bit masks and the
     pooling kernels at the sizes the benchmark runs."""
     from oracle import reference_nets as RNets
@@ -103,6 +110,9 @@ def test_resnet34_full_baseline_size_forward_backward_vs_oracle():
     net, _ = _product_net(S, N)
     synth.fill_module_(net, seed=5)
     onet.train(); onet64.train(); net.train()
+    feats = {}                                     # the features each net feeds its head (for the gate analysis below)
+    for tag, m in (('cpu32', onet), ('f64', onet64), ('hip', net)):
+        dict(m.named_modules())['head.2'].register_forward_hook(lambda mod, i, o, tag=tag: feats.update({tag: i[0].detach().double().cpu()}))   # (returns None: output untouched)
     lp = net(x.to(DEV)); loss_p = nn.CrossEntropyLoss()(lp, y.to(DEV)); loss_p.backward()
     lo = onet(x); loss_o = nn.CrossEntropyLoss()(lo, y); loss_o.backward()
     l64 = onet64(x.double()); loss_64 = nn.CrossEntropyLoss()(l64, y); loss_64.backward()
@@ -110,13 +120,45 @@ def test_resnet34_full_baseline_size_forward_backward_vs_oracle():
     gap = (lo.detach().double() - l64).abs().max().item()
     assert (lp.detach().cpu().double() - l64).abs().max().item() <= 3 * gap + 1e-3 * l64.abs().max().item(), 'logits'
     assert abs(loss_p.item() - loss_64.item()) <= 3 * abs(loss_o.item() - loss_64.item()) + 1e-3 * abs(loss_64.item()), 'loss'
-    worst, worst_ratio = 0.0, 0.0
+    worst, worst_ratio, rows = 0.0, 0.0, []
     for (n, po), (_, p64), (_, pp) in zip(onet.named_parameters(), onet64.named_parameters(), net.named_parameters()):
         g64, go, gp = p64.grad, po.grad.double(), pp.grad.detach().cpu().double()
         err_hip, err_cpu, ref = (gp - g64).norm().item(), (go - g64).norm().item(), g64.norm().item()
         worst = max(worst, err_hip / max(ref, 1e-300))
         worst_ratio = max(worst_ratio, err_hip / max(err_cpu, 1e-300))
-        assert err_hip <= 3 * err_cpu + 1e-3 * ref, '%s: |hip-f64| %.3e vs |cpu32-f64| %.3e (|f64| %.3e)' % (n, err_hip, err_cpu, ref)
+        rows.append((err_hip / (3 * err_cpu + 1e-3 * ref + 1e-300), n, err_hip, err_cpu, ref))
+    rows.sort(reverse=True)
+    print('closest to the bound (|hip-f64| / bound, tensor, |hip-f64|, |cpu32-f64|, |f64|):')
+    for r in rows[:6]:
+        print('  %.3f  %-40s %.3e %.3e %.3e' % r)
+    bad = [r for r in rows if r[0] > 1.0]
+    if bad and all(r[1].startswith('head.2.') for r in bad):
+        fc64 = dict(onet64.named_modules())['head.2']
+
+        def pre(f):
+            with torch.no_grad():
+                return fc64.lins[0].lin(F.batch_norm(f, None, None, fc64.pre_bn.weight, fc64.pre_bn.bias, True, 0.1, fc64.pre_bn.eps))
+        p64, p32, ph = pre(feats['f64']), pre(feats['cpu32']), pre(feats['hip'])
+        flips = (ph > 0) != (p64 > 0)
+        zero_tol = 3 * (p32 - p64).abs().max().item() + 1e-3 * p64.abs().max().item()
+        print('head gates that differ from fp64: %d; largest |p_f64| among them %.3e (undetermined below %.3e)'
+              % (int(flips.sum()), p64[flips].abs().max().item() if flips.any() else 0.0, zero_tol))
+        assert flips.any() and p64[flips].abs().max().item() <= zero_tol, 'head gradients off without an undetermined gate: %r' % (bad,)
+        hook = fc64.lins[0].lin.register_forward_hook(lambda m, i, o: torch.where(flips, o + (ph - o).detach(), o))
+        for p in fc64.parameters():
+            p.grad = None
+        nn.CrossEntropyLoss()(fc64(feats['f64']), y).backward()
+        hook.remove()
+        g64m = {'head.2.' + n: p.grad for n, p in fc64.named_parameters()}
+        gp = {n: p.grad.detach().cpu().double() for n, p in net.named_parameters() if n.startswith('head.2.')}
+        still = []
+        for r in bad:
+            err = (gp[r[1]] - g64m[r[1]]).norm().item()
+            print('  %-40s |hip - f64 with the product gates| %.3e (bound %.3e)' % (r[1], err, 3 * r[3] + 1e-3 * r[4]))
+            if err > 3 * r[3] + 1e-3 * r[4]:
+                still.append(r)
+        bad = still
+    assert not bad, '; '.join('%s: |hip-f64| %.3e vs |cpu32-f64| %.3e (|f64| %.3e)' % r[1:] for r in bad)
     for (n, bo), (_, bp) in zip(onet.named_buffers(), net.named_buffers()):
         assert_close(bp, bo, 1e-4, 1e-5, 'buffer ' + n)
     print('worst relative gradient error vs fp64 %.2e; worst |hip-f64| / |cpu32-f64| %.2f' % (worst, worst_ratio))

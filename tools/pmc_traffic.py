@@ -11,7 +11,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV = ('igemm_', 'wino_kernel', 'wino_filter_kernel', 'slab_reduce_kernel', 'splitk_reduce_kernel', 'weight_transpose_kernel')   # everything a conv C call launches
+CONV = ('igemm_', 'wino_kernel', 'wino2_kernel', 'wino_filter_kernel', 'wino2_filter_kernel', 'slab_reduce_kernel', 'splitk_reduce_kernel', 'weight_transpose_kernel')   # everything a conv C call launches
 
 
 def load(path, name):
@@ -34,12 +34,12 @@ def main(fetch_csv, write_csv, tag='r2'):
         out[name] = (tot, n)
     (F, nF), (W, nW) = out['FETCH_SIZE'], out['WRITE_SIZE']
     is_conv = lambda k: any(t in k for t in CONV)
-    main_launch = lambda k: 'igemm_' in k or 'wino_kernel' in k   # one GEMM kernel per conv C call; reduces / transposes / filter transforms ride along
+    main_launch = lambda k: 'igemm_' in k or 'wino_kernel' in k or 'wino2_kernel' in k   # one GEMM kernel per conv C call; reduces / transposes / filter transforms ride along
     launches = sum(nF[k] for k in F if main_launch(k))
     fetch = sum(F[k] for k in F if is_conv(k)) * 1024.0
     write = sum(W[k] for k in W if is_conv(k)) * 1024.0
     js = {
-        'kernel': 'igemm_taps_kernel / wino_kernel / igemm_wgrad_kernel (+ their slab reduces, filter transforms and the dgrad weight transposes): every conv / linear launch of bench.py',
+        'kernel': 'igemm_taps_kernel / wino_kernel / wino2_kernel / igemm_wgrad_kernel (+ their slab reduces, filter transforms and the dgrad weight transposes): every conv / linear launch of bench.py',
         'command': 'rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none',
         'bs': 64, 'sz': 224, 'gpus': 1,
         'fetch_size_bytes_per_launch_raw': fetch / launches,
