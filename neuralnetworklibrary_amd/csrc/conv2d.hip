@@ -826,23 +826,24 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
 // staged element, single accumulator chains: folded into nnl_wino_plan_time_us), both launches carry ~6 us the model does not see, and the filter transform adds a launch (3 us)
 // plus 21 * Cin * Nc * 4 bytes of traffic.  A 3 % margin keeps coin-flip cases on the direct kernel.
 // Returns 0 (direct kernel), 1 (1-D F(2,3), wino.hip) or 2 (2-D F(2x2,3x3), wino2.hip).  The 2-D kernel issues 2.25x fewer multiplies
-// but works on a quarter of the direct kernel's tiles with four-pixel slabs and five loads per k step: it MEASURED faster than the
-// 1-D one from ~500 quad tiles up (profiles/r3_wino2d_probe.log, r3_wino2d_sizes.log: -9 ... -20 % at 512 ... 2048 tiles, +5 ... +25 %
-// below 400), so that is the rule (NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal).
+// on a quarter of the direct kernel's tiles with four-pixel slabs and five loads per k step; its planner predicts absolute launch
+// times from a model fitted to forced-schedule sweeps (wino2.hip: w2_cost) and it is taken where that prediction beats the 1-D
+// kernel's — and only where the 1-D kernel already beats the direct one: the model was not fitted on the tiny grids the direct kernel
+// keeps (profiles/r3_wino2d_*.log: -13 ... -20 % against the 1-D kernel per ResNet-34 stage at 64 images, -3 ... -9 % at 32).
+// NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal.
 static int wino_mode(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
   if (!nnl_wino_ok(N, H, W, Cin, Nc, R, S, stride, pad)) return 0;
   const int e = NNL_ENV_INT("NNL_CONV_WINO", 1);
   const bool two_ok = nnl_wino2_ok(N, H, W, Cin, Nc, R, S, stride, pad);
   if (e == 3) return two_ok ? 2 : 1;
-  if (e != 2) {
-    const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
-    const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
-    if (!(t_w < 0.97 * t_d)) return 0;
-  } else {
-    return 1;
-  }
+  if (e == 2) return 1;
+  const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
+  const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
+  if (!(t_w < 0.97 * t_d)) return 0;
   const long quad_tiles = nnl_cdiv((long)N * ((H + 1) / 2) * ((W + 1) / 2), 64L) * nnl_cdiv((long)Nc, 64L);
-  if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 500)) return 2;
+  if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 0) &&
+      nnl_wino2_plan_time_us(N, H, W, Cin, Nc) < 0.9 * t_w)      // 10 % predicted margin: at 32 images the two are within 5 % either way
+    return 2;
   return 1;
 }
 static size_t wino_mode_workspace(int mode, int N, int H, int W, int Cin, int Nc) {

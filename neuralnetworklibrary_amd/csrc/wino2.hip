@@ -348,60 +348,62 @@ struct W2Plan {
   double t_us;
 };
 
+// Cost of one schedule (us), fitted to 477 forced-schedule timings of this kernel (tools/wino2_plan_sweep.py, profiles/r3_wino2d_plan_sweep.log:
+// five layer shapes x 16 / 32 / 64 images x both k blocks x 21 (main slices, tail slices) settings, rms error 9 %).  A CU's busiest set of
+// workgroups — m main + q tail blocks, up to `occ` of them resident — costs W * (b + a / c): W their k iterations, c = min(occ, m + q)
+// the co-resident count; `a` is the per-iteration latency a lone workgroup cannot hide (five loads, one barrier), `b` the MFMA / LDS
+// share that co-resident workgroups divide.  Plus a fixed cost per workgroup generation (prologue, 16 folds, four-tile epilogue),
+// the slab round trips at a fitted 11.7 TB/s and 10 us of launch + filter pre-pass.
+double w2_cost(long T, long gn, long M4, int Nc, long I, int bk, int ks, int S, W2Plan* out) {
+  const double a = bk == 32 ? 0.363 : 0.226, b = bk == 32 ? 0.490 : 0.243, tfix = bk == 32 ? 12.3 : 15.0;
+  const long occ = (bk == 16 && NNL_ENV_INT("NNL_WINO2_OCC", 4) != 3) ? 4 : 3;
+  long n_main = ((T * ks / kCUs) * kCUs / ks / gn) * gn;
+  if (n_main > T) n_main = T;
+  const long tail = T - n_main;
+  if (tail == 0 && S > 1) return -1.0;
+  const long m = nnl_cdiv(n_main * ks, (long)kCUs), q = nnl_cdiv(tail * S, (long)kCUs);
+  const long W = m * nnl_cdiv(I, (long)ks) + q * nnl_cdiv(I, (long)S), nb = m + q;
+  const double c = (double)(nb < occ ? nb : occ);
+  const long row0 = (n_main / gn) * 64 < M4 ? (n_main / gn) * 64 : M4;
+  const double main_b = ks > 1 ? (2.0 * ks + 1) * row0 * 4 * Nc * 4 : 0;
+  const double tail_b = (S > 1 && tail) ? (2.0 * S + 1) * (M4 - row0) * 4 * Nc * 4 : 0;
+  if (out) {
+    out->bk = bk; out->on = (ks > 1 || (S > 1 && tail)) ? 1 : 0;
+    out->main_ks = ks; out->n_main_tiles = (int)n_main; out->tail_slices = tail ? S : 1; out->tail_row0 = (int)row0;
+    out->main_floats = ks > 1 ? (size_t)ks * row0 * 4 * Nc : 0;
+    out->tail_floats = (S > 1 && tail) ? (size_t)S * (M4 - row0) * 4 * Nc : 0;
+  }
+  return W * (b + a / c) + tfix * nb / c + (main_b + tail_b) / 11.7e6 + 10.0;
+}
+
 W2Plan wino2_plan(long M4, int Nc, int C) {
   W2Plan best{};
   const long gm = nnl_cdiv(M4, 64), gn = nnl_cdiv(Nc, 64), T = gm * gn;
   const int e_bk = NNL_ENV_INT("NNL_WINO2_BK", 0);
-  best.bk = (e_bk == 16 || e_bk == 32) ? e_bk : 16;
-  if (C % best.bk != 0) best.bk = 16;
-  const int bk = best.bk;
-  const long I = 16L * (C / bk);
-  const double c_it = bk == 32 ? 0.60 : 0.30;
-  const long occ = (bk == 16 && NNL_ENV_INT("NNL_WINO2_OCC", 4) != 3) ? 4 : 3;
-  auto wave_iters = [&](long blocks, long iters) {
-    if (blocks <= 0) return 0.0;
-    const long cap = occ * kCUs;
-    const long full = blocks / cap, rem = blocks - full * cap;
-    return (double)(full * occ + nnl_cdiv(rem, (long)kCUs)) * iters;
-  };
-  const double plain = wave_iters(T, I) * c_it;
-  best.t_us = plain;
-  if (NNL_ENV_INT("NNL_WINO_BALANCE", 1) == 0) return best;
-  double best_t = plain * 0.99;
-  const int plan_extra = 2;
-  const double plan_bw = 16000.0e3;
   const int f_ks = NNL_ENV_INT("NNL_WINO_PLAN_KS", 0), f_S = NNL_ENV_INT("NNL_WINO_PLAN_S", 0);
-  if (f_ks > 0 || f_S > 0) best_t = 1e300;
-  for (int ks = 1; ks <= 4; ks *= 2) {
-    if (f_ks > 0 && ks != f_ks) continue;
-    if (I / ks < 8) break;
-    const long units = T * ks;
-    long n_main = ((units / kCUs) * kCUs / ks / gn) * gn;
-    if (n_main > T) n_main = T;
-    const long tail = T - n_main;
-    const long it_main = nnl_cdiv(I, (long)ks);
-    static const int kSlices[] = {1, 2, 3, 4, 6, 8, 9, 12, 16, 18, 24, 32, 36, 48};
-    for (int S : kSlices) {
-      if (tail == 0 && S > 1) break;
-      if (S > 1 && I / S < 4) break;
-      if (f_S > 0 && tail > 0 && S != f_S) continue;
-      const long it_tail = nnl_cdiv(I, (long)S);
-      double t = (wave_iters(n_main * ks, it_main) + wave_iters(tail * S, it_tail + (S > 1 ? plan_extra : 0))) * c_it;
-      const long row0 = (n_main / gn) * 64 < M4 ? (n_main / gn) * 64 : M4;
-      const double main_b = ks > 1 ? (2.0 * ks + 1) * row0 * 4 * Nc * 4 : 0;
-      const double tail_b = S > 1 ? (2.0 * S + 1) * (M4 - row0) * 4 * Nc * 4 : 0;
-      t += (main_b + tail_b) / plan_bw + (ks > 1 ? 1 : 0) + (S > 1 && tail ? 1 : 0);
-      if (t < best_t) {
-        best_t = t;
-        best.t_us = t;
-        best.on = 1; best.main_ks = ks; best.n_main_tiles = (int)n_main; best.tail_slices = tail ? S : 1;
-        best.tail_row0 = (int)row0;
-        best.main_floats = ks > 1 ? (size_t)ks * row0 * 4 * Nc : 0;
-        best.tail_floats = (S > 1 && tail) ? (size_t)S * (M4 - row0) * 4 * Nc : 0;
+  const bool balance = NNL_ENV_INT("NNL_WINO_BALANCE", 1) != 0;
+  double best_t = 1e300;
+  static const int kSlices[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  for (int bk = 16; bk <= 32; bk *= 2) {
+    if (C % bk != 0 || ((e_bk == 16 || e_bk == 32) && bk != e_bk && C % e_bk == 0)) continue;
+    const long I = 16L * (C / bk);
+    for (int ks = 1; ks <= 4; ks *= 2) {
+      if (ks > 1 && (!balance || I / ks < 8)) break;
+      if (f_ks > 0 && ks != f_ks && balance) continue;
+      for (int S : kSlices) {
+        if (S > 1 && (!balance || I / S < 4)) break;
+        W2Plan cand{};
+        const double t = w2_cost(T, gn, M4, Nc, I, bk, ks, S, &cand);
+        if (t < 0) break;                                                  // no tail tiles: S is meaningless beyond 1
+        if (f_S > 0 && balance && cand.n_main_tiles < T && S != f_S) continue;
+        if (t < best_t) { best_t = t; best = cand; best.t_us = t; }
       }
     }
   }
-  if (best.on && best.main_ks == 1 && best.tail_slices == 1) best.on = 0;
+  if (best_t == 1e300) {                                                   // (forced settings the shape does not allow)
+    const int bk = (e_bk == 32 && C % 32 == 0) ? 32 : 16;
+    best.t_us = w2_cost(T, gn, M4, Nc, 16L * (C / bk), bk, 1, 1, &best);
+  }
   return best;
 }
 
