@@ -25,6 +25,7 @@ struct Wino2Params {
   const float* add;
   unsigned a_bytes, b_bytes;
   int H, W, C, H2, W2; // H2 x W2 quads per image
+  int ch;              // channel chunk of the k order (a multiple of BK dividing C)
   int M4;              // N * H2 * W2 rows
   int Nc;
   int relu;
@@ -165,7 +166,12 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
   f32x16 y00, y01, y10, y11, tm;
 #pragma unroll
   for (int e = 0; e < 16; ++e) { y00[e] = 0.f; y01[e] = 0.f; y10[e] = 0.f; y11[e] = 0.f; tm[e] = 0.f; }
-  const int csteps = p.C / BK, nk_all = 16 * csteps;
+  // k order: channel CHUNK (p.ch channels) outermost, the 16 positions, the chunk's BK blocks innermost.  Default chunk = all of C
+  // (position-major: one fold per position).  Smaller chunks bring the four uses of a patch pixel closer together (the position-
+  // major order streams the input 16 times from beyond the L2: profiles/r3_traffic.json) at the price of a fold every chunk —
+  // measured SLOWER (NNL_WINO2_CHUNK=64: 28^2 stage -5 %, 14^2 stage -7 %, profiles/r3_wino2d_chunk_ab_bs64.log): the re-reads hit the
+  // Infinity Cache and are not what bounds the loop.
+  const int csteps = p.C / BK, nk_all = 16 * csteps, cpc = p.ch / BK, per_chunk = 16 * cpc;
   int kt0 = 0, nk = nk_all;
   if (partial) {
     const int per = (nk_all + nslices - 1) / nslices;
@@ -174,11 +180,16 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     if (nk < 0) nk = 0;
   }
   const int kend = kt0 + nk;
-  int t_nx = kt0 / csteps, c_nx = (kt0 - t_nx * csteps) * BK;
-  int t_cur = t_nx, c_cur = c_nx;
+  int chunk_nx = kt0 / per_chunk, t_nx = (kt0 - chunk_nx * per_chunk) / cpc, cs_nx = kt0 - chunk_nx * per_chunk - t_nx * cpc;
+  int c_nx = chunk_nx * p.ch + cs_nx * BK;
+  int t_cur = t_nx, cs_cur = cs_nx;
   auto advance = [&]() {
-    c_nx += BK;
-    if (c_nx >= p.C) { c_nx = 0; ++t_nx; set_pos(t_nx); }
+    if (++cs_nx == cpc) {
+      cs_nx = 0;
+      if (++t_nx == 16) { t_nx = 0; ++chunk_nx; }
+      set_pos(t_nx);
+    }
+    c_nx = chunk_nx * p.ch + cs_nx * BK;
   };
   if (nk > 0) {
     set_pos(t_nx);
@@ -199,8 +210,7 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-    c_cur += BK;
-    if (c_cur >= p.C || kt + 1 == kend) {             // the position's channel loop (or this slice of it) is over: fold tm in
+    if (++cs_cur == cpc || kt + 1 == kend) {          // the position's blocks of this chunk (or this slice of them) are done: fold tm in
       const int xi = t_cur >> 2, nu = t_cur & 3;
       const float cp0 = xi < 3 ? 1.f : 0.f, cp1 = xi == 0 ? 0.f : (xi == 2 ? -1.f : 1.f);
       const float cq0 = nu < 3 ? 1.f : 0.f, cq1 = nu == 0 ? 0.f : (nu == 2 ? -1.f : 1.f);
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
         y10[e] = __builtin_fmaf(k10, tm[e], y10[e]); y11[e] = __builtin_fmaf(k11, tm[e], y11[e]);
         tm[e] = 0.f;
       }
-      c_cur = 0; ++t_cur;
+      cs_cur = 0; t_cur = (t_cur + 1) & 15;
     }
   }
 
@@ -441,6 +451,10 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
   Wino2Params p{};
   p.a = q.in; p.b = q.u_pre ? q.u_pre : u; p.y = q.out; p.bias = q.bias; p.add = q.add;
   p.a_bytes = (unsigned)((long)q.N * q.H * q.W * q.Cin * 4); p.b_bytes = (unsigned)((long)q.Nc * 16 * q.Cin * 4);
+  {
+    const int e_ch = NNL_ENV_INT("NNL_WINO2_CHUNK", 0);                  // 0: the whole C (position-major order); else a multiple of 32 dividing C
+    p.ch = (e_ch > 0 && e_ch % 32 == 0 && q.Cin % e_ch == 0) ? e_ch : q.Cin;
+  }
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.H2 = (q.H + 1) / 2; p.W2 = (q.W + 1) / 2; p.M4 = (int)M4; p.Nc = q.Nc; p.relu = q.relu;
   p.grid_m = (int)nnl_cdiv(M4, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
   p.bn_part = q.bn_part; p.bn_pivot = q.bn_pivot;

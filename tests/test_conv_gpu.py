@@ -342,12 +342,14 @@ def test_prepared_winograd_filters_match_per_call_transform(mode, monkeypatch):
 
 @pytest.mark.parametrize('case', [(2, 64, 12, 10, 64, None), (3, 32, 9, 7, 36, None), (4, 128, 14, 14, 128, (2, 4)), (1, 16, 2, 2, 8, None),
                                   (2, 64, 17, 33, 96, (1, 3))], ids=str)
-def test_winograd_2d_debug_entry(case, monkeypatch):
+@pytest.mark.parametrize('chunk', ['0', '32'], ids=['position-major', 'chunk32'])
+def test_winograd_2d_debug_entry(case, chunk, monkeypatch):
     """The 2-D F(2x2, 3x3) kernel (csrc/wino2.hip) through its debug entry nnl_debug_conv_wino2_fwd (the dispatcher takes it from ~500
     quad tiles up; profiles/README.md has the measurements): forward with bias / addend / ReLU / BatchNorm partial sums and the flipped dgrad
     filter, odd heights and widths, plain grid and forced k-slicing (in-kernel slab fix-up), against torch CPU fp32."""
     from neuralnetworklibrary_amd._lib import lib, ptr, stream, check
     N, C, H, W, K, forced = case
+    monkeypatch.setenv('NNL_WINO2_CHUNK', chunk)              # k order: whole C per position (default) / 32-channel chunks outermost
     if forced:
         monkeypatch.setenv('NNL_WINO_PLAN_KS', str(forced[0])); monkeypatch.setenv('NNL_WINO_PLAN_S', str(forced[1]))
     lib.nnl_reload_env()
@@ -394,4 +396,5 @@ def test_winograd_2d_debug_entry(case, monkeypatch):
         assert_close(dx, refdx, rtol=1e-4, atol=1e-5 * refdx.abs().max().item(), msg='2-D Winograd dgrad filter')
     if forced:
         monkeypatch.delenv('NNL_WINO_PLAN_KS'); monkeypatch.delenv('NNL_WINO_PLAN_S')
+    monkeypatch.delenv('NNL_WINO2_CHUNK')
     lib.nnl_reload_env()
