@@ -26,6 +26,7 @@ struct Wino2Params {
   unsigned a_bytes, b_bytes;
   int H, W, C, H2, W2; // H2 x W2 quads per image
   int ch;              // channel chunk of the k order (a multiple of BK dividing C)
+  int prio;            // 1: raise the wave priority around the MFMA block (NNL_WINO2_PRIO)
   int M4;              // N * H2 * W2 rows
   int Nc;
   int relu;
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     load_tile(c_nx);
     const float sr_n = sr, sc_n = sc;
     __builtin_amdgcn_sched_barrier(0);
+    if (p.prio) __builtin_amdgcn_s_setprio(2);         // (A/B: NNL_WINO2_PRIO — the MFMA block of this wave ahead of the other waves' staging)
     compute(cur, tm);
+    if (p.prio) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     sr_ld = sr_n; sc_ld = sc_n;
     store_tile(cur ^ 1);
@@ -454,6 +457,7 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
   {
     const int e_ch = NNL_ENV_INT("NNL_WINO2_CHUNK", 0);                  // 0: the whole C (position-major order); else a multiple of 32 dividing C
     p.ch = (e_ch > 0 && e_ch % 32 == 0 && q.Cin % e_ch == 0) ? e_ch : q.Cin;
+    p.prio = NNL_ENV_INT("NNL_WINO2_PRIO", 0);
   }
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.H2 = (q.H + 1) / 2; p.W2 = (q.W + 1) / 2; p.M4 = (int)M4; p.Nc = q.Nc; p.relu = q.relu;
   p.grid_m = (int)nnl_cdiv(M4, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
