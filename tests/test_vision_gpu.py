@@ -169,30 +169,34 @@ def _oracle_curve_fp32(g, N, S, steps, lr, wd, perturb_seed=None):
     perturb_seed: start from weights moved by -1 / 0 / +1 ulp at random — an input perturbation BELOW fp32 resolution, i.e. the
     textbook yardstick of conditioning: a backward-stable fp32 implementation is exact for inputs perturbed at that level."""
     from oracle import reference_math as RM, reference_nets as RNets
-    torch.set_num_threads(min(torch.get_num_threads(), 16))
-    onet = RNets.ImageClassificationNet(RNets.resnet34(), 2, 512, drops=(0., 0.), probe_sz=(S, S))
-    synth.fill_module_(onet, seed=5)
-    if perturb_seed is not None:
-        gen = torch.Generator().manual_seed(perturb_seed)
-        with torch.no_grad():
-            for p in onet.parameters():
-                p.mul_(1.0 + 2.0 ** -23 * (torch.randint(0, 3, p.shape, generator=gen).float() - 1.0))
-    onet.train()
-    names = [n for n, _ in onet.named_parameters()]
-    params = [p for _, p in onet.named_parameters()]
-    group = lambda n: 2 if n.startswith('head') else (0 if int(n.split('.')[1]) < 6 else 1)      # default_split: body[:6], body[6:], head
-    lrs = [lr[group(n)] for n in names]
-    state = RM.OptimState(params)
-    out = []
-    for i in range(steps):
-        x, y = synth.synth_input((N, 3, S, S), 130 + i % 4), (torch.arange(N) * 7 + i % 4) % 2
-        for p in params:
-            p.grad = None
-        loss = nn.CrossEntropyLoss()(onet(x), y)
-        loss.backward()
-        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [wd] * len(params), 'sgd')
-        out.append(loss.item())
-    return np.array(out)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 16))          # (restored below: a changed thread count changes the rounding of every later CPU oracle run)
+    try:
+        onet = RNets.ImageClassificationNet(RNets.resnet34(), 2, 512, drops=(0., 0.), probe_sz=(S, S))
+        synth.fill_module_(onet, seed=5)
+        if perturb_seed is not None:
+            gen = torch.Generator().manual_seed(perturb_seed)
+            with torch.no_grad():
+                for p in onet.parameters():
+                    p.mul_(1.0 + 2.0 ** -23 * (torch.randint(0, 3, p.shape, generator=gen).float() - 1.0))
+        onet.train()
+        names = [n for n, _ in onet.named_parameters()]
+        params = [p for _, p in onet.named_parameters()]
+        group = lambda n: 2 if n.startswith('head') else (0 if int(n.split('.')[1]) < 6 else 1)      # default_split: body[:6], body[6:], head
+        lrs = [lr[group(n)] for n in names]
+        state = RM.OptimState(params)
+        out = []
+        for i in range(steps):
+            x, y = synth.synth_input((N, 3, S, S), 130 + i % 4), (torch.arange(N) * 7 + i % 4) % 2
+            for p in params:
+                p.grad = None
+            loss = nn.CrossEntropyLoss()(onet(x), y)
+            loss.backward()
+            RM.optimizer_step(params, [p.grad for p in params], state, lrs, [wd] * len(params), 'sgd')
+            out.append(loss.item())
+        return np.array(out)
+    finally:
+        torch.set_num_threads(threads)
 
 
 def test_g13_resnet34_20_step_loss_curve_at_baseline_size():
