@@ -27,6 +27,7 @@ struct Wino2Params {
   int H, W, C, H2, W2; // H2 x W2 quads per image
   int ch;              // channel chunk of the k order (a multiple of BK dividing C)
   int prio;            // 1: raise the wave priority around the MFMA block (NNL_WINO2_PRIO)
+  int fold_skip;       // 1 (default): a position is folded only into the output tiles it feeds (NNL_WINO2_FOLD_SKIP=0: all four, A/B)
   int M4;              // N * H2 * W2 rows
   int Nc;
   int relu;
@@ -218,12 +219,25 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
       const float cp0 = xi < 3 ? 1.f : 0.f, cp1 = xi == 0 ? 0.f : (xi == 2 ? -1.f : 1.f);
       const float cq0 = nu < 3 ? 1.f : 0.f, cq1 = nu == 0 ? 0.f : (nu == 2 ? -1.f : 1.f);
       const float k00 = cp0 * cq0, k01 = cp0 * cq1, k10 = cp1 * cq0, k11 = cp1 * cq1;
+      // coefficients 0 / +-1, wave-uniform: corner positions feed one output tile, edge positions two, centre positions four
+      if (k00 != 0.f || !p.fold_skip) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        y00[e] = __builtin_fmaf(k00, tm[e], y00[e]); y01[e] = __builtin_fmaf(k01, tm[e], y01[e]);      // coefficients 0 / +-1
-        y10[e] = __builtin_fmaf(k10, tm[e], y10[e]); y11[e] = __builtin_fmaf(k11, tm[e], y11[e]);
-        tm[e] = 0.f;
+        for (int e = 0; e < 16; ++e) y00[e] = __builtin_fmaf(k00, tm[e], y00[e]);
       }
+      if (k01 != 0.f || !p.fold_skip) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y01[e] = __builtin_fmaf(k01, tm[e], y01[e]);
+      }
+      if (k10 != 0.f || !p.fold_skip) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y10[e] = __builtin_fmaf(k10, tm[e], y10[e]);
+      }
+      if (k11 != 0.f || !p.fold_skip) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y11[e] = __builtin_fmaf(k11, tm[e], y11[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tm[e] = 0.f;
       cs_cur = 0; t_cur = (t_cur + 1) & 15;
     }
   }
@@ -458,6 +472,7 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
     const int e_ch = NNL_ENV_INT("NNL_WINO2_CHUNK", 0);                  // 0: the whole C (position-major order); else a multiple of 32 dividing C
     p.ch = (e_ch > 0 && e_ch % 32 == 0 && q.Cin % e_ch == 0) ? e_ch : q.Cin;
     p.prio = NNL_ENV_INT("NNL_WINO2_PRIO", 0);
+    p.fold_skip = NNL_ENV_INT("NNL_WINO2_FOLD_SKIP", 1);
   }
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.H2 = (q.H + 1) / 2; p.W2 = (q.W + 1) / 2; p.M4 = (int)M4; p.Nc = q.Nc; p.relu = q.relu;
   p.grid_m = (int)nnl_cdiv(M4, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
