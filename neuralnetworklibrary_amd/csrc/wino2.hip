@@ -9,6 +9,9 @@
 // A GEMM row is a 2x2 output QUAD (n, i, j); per row 16 positions of Cin channels against 36 for the direct kernel: 4 MFMA k
 // steps per output instead of 9 (2.25x fewer; 1-D: 6).  All positions accumulate into one tile that is folded into the four
 // output tiles with the position's coefficients when the position's channel loop ends.  Tile = 64 quads x 64 channels, 4 waves.
+// Replaces cuDNN's Winograd convolutions in the reference's 3x3 layers (retinanet.py:43-59,77-97,126-148,187-217,260-295), where the
+// dispatcher (conv2d.hip: wino_mode) predicts it >= 10 % under the 1-D kernel.  Schedule: the balanced plan of the other conv kernels
+// with its own fitted cost model (w2_cost below).  Measured: profiles/README.md, r3_wino2d_*.
 #include "wino.h"
 #include "wino_filter.h"
 #include "igemm_taps.h"
