@@ -177,6 +177,12 @@ size_t nnl_debug_conv_wino2_workspace_bytes(int N, int H, int W, int C, int K);
 int nnl_debug_conv_wino2_fwd(const float* x, const float* filt, const float* bias, const float* add, float* y, void* ws,
                             size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
                             int H, int W, int C, int K, int relu, int flip, void* stream);
+/* the same through the spatially staged 2-D kernel (csrc/wino2s.hip: raw input rows by LDS-DMA, pre-tiled U) */
+size_t nnl_debug_conv_wino2s_workspace_bytes(int N, int H, int W, int C, int K);
+int nnl_debug_conv_wino2s_fwd(const float* x, const float* filt, const float* bias, const float* add, float* y, void* ws,
+                             size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
+                             int H, int W, int C, int K, int relu, int flip, void* stream);
+double nnl_debug_w2s_model(long T, long gn, long M4, int Nc, long I, long P, int ks, int S, const double* prm);   /* host-only schedule model of wino2s.hip */
 int nnl_debug_conv_plan_times(int N, int H, int W, int C, int K, double* out);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
  * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */

@@ -53,6 +53,9 @@ SIGNATURES = {
     'nnl_debug_conv_wino_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
     'nnl_debug_conv_wino2_workspace_bytes': (sz, [C.c_int] * 5),
     'nnl_debug_conv_wino2_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
+    'nnl_debug_conv_wino2s_workspace_bytes': (sz, [C.c_int] * 5),
+    'nnl_debug_conv_wino2s_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
+    'nnl_debug_w2s_model': (C.c_double, [C.c_long] * 3 + [C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     'nnl_debug_conv_plan_times': (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_double)]),
     'nnl_conv2d_fwd': (C.c_int, [c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), C.c_int, c_p, sz, c_p, c_p, c_p, C.POINTER(i32), c_p]),
     'nnl_conv2d_weight_transpose': (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p]),

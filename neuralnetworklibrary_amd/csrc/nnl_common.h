@@ -37,6 +37,7 @@ static inline int64_t nnl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Tuning / A-B switches (NNL_* environment variables): read ONCE per site, not per launch (a getenv per call sits on the host's
 // launch path).  nnl_reload_env() — exported for tests and the A/B tools — makes every site read its variable again.
 int nnl_env_cached(const char* name, int dflt, int* value, int* generation);
+int nnl_env_generation();          // bumped by nnl_reload_env(): caches of env-dependent plans key on it
 #define NNL_ENV_INT(name, dflt) ([]() -> int { static int v_ = 0, g_ = -1; return nnl_env_cached(name, dflt, &v_, &g_); }())
 
 // optional per-launch profiling with HIP events on the launch stream (bench.py roofline leg)

@@ -28,6 +28,7 @@ int nnl_env_cached(const char* name, int dflt, int* value, int* generation) {
   return *value;
 }
 extern "C" int nnl_reload_env(void) { ++g_env_generation; return NNL_OK; }
+int nnl_env_generation() { return g_env_generation; }
 extern "C" const char* nnl_last_error(void) { return g_err; }
 
 // ---- profiling: a bounded pool of event pairs, recorded on the stream each kernel is launched on ----
