@@ -143,23 +143,25 @@ int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv
  *   flip == 1: filt = wt[K,3,3,C] read as wt[.,2-r,2-s,.] (the dgrad filter: x = dy, K = C_in of the layer, wt = W^T[C,R,S,K]).
  *   ws: nnl_debug_conv_wino_workspace_bytes bytes; counters: n_counters zeroed int32 (zero again on return) or NULL (plain grid);
  *   bn_part / bn_pivot (both or neither): BatchNorm partial statistics as for nnl_conv2d_fwd, one per 64 output pairs.
- * nnl_debug_conv_plan_times: out[0] / out[1] = predicted launch time (us) of the direct / the Winograd kernel for that problem;
+ * nnl_debug_conv_plan_times: out[0..3] (FOUR doubles) = predicted launch time (us) of the direct / the 1-D Winograd / the 2-D / the spatially
+ *   staged 2-D kernel (-1: shape not served) for that problem;
  *   returns 1 when the dispatcher would pick the Winograd kernel, else 0. */
 /* Prepared filters.  The transformed filter of a layer depends on its weights only, so a caller that knows all its layers can
  * transform them in ONE launch per step instead of one per convolution call:
  *   nnl_conv2d_wino_preferred(g, dgrad): which kernel nnl_conv2d_fwd (dgrad = 0) / nnl_conv2d_dgrad (dgrad = 1) takes for geometry g (given
- *     the workspace of the size query): 0 direct, 1 the 1-D F(2,3) Winograd kernel, 2 the 2-D F(2x2,3x3) one;
+ *     the workspace of the size query): 0 direct, 1 the 1-D F(2,3) Winograd kernel, 2 the 2-D F(2x2,3x3) one, 3 the spatially staged 2-D one;
  *   nnl_wino_filter_multi: descriptor d transforms src [rows,3,3,ch] into dst [rows,4,3,ch]; flip = 0 with src = w[K,3,3,C]
  *     (rows = K, ch = C) gives the FORWARD filter, flip = 1 with src = W^T[C,3,3,K] (rows = C, ch = K: nnl_conv2d_weight_transpose)
  *     the DGRAD filter; block_desc[b] = descriptor served by block b, first_block = its first block, ceil(rows*3*ch / 256) blocks each;
  *   nnl_conv2d_fwd_pre / nnl_conv2d_dgrad_pre: nnl_conv2d_fwd / nnl_conv2d_dgrad with `u` = that prepared filter (NULL: exactly the
  *     plain entry points); u is used only when a Winograd kernel is taken and must then hold the layout of THAT kernel (nnl_conv2d_wino_preferred:
- *     1 -> rows * 12 * ch floats, 2 -> rows * 16 * ch floats, two_d = 1). */
+ *     1 -> rows * 12 * ch floats, 2 -> rows * 16 * ch floats, two_d = 1; 3 (the spatially staged 2-D kernel, csrc/wino2s.hip) ->
+ *     ceil(rows / 64) * 64 * 16 * ch floats in its pre-tiled layout, two_d = 2, ceil(rows / 64) * ceil(ch / 16) blocks). */
 typedef struct {
   const float* src;
   float* dst;
   int32_t rows, ch, flip, first_block;
-  int32_t two_d, reserved;                   /* two_d = 1: dst [rows,16,ch] for the 2-D F(2x2,3x3) kernel, ceil(rows*ch / 256) blocks */
+  int32_t two_d, reserved;                   /* two_d = 1: dst [rows,16,ch] for the 2-D F(2x2,3x3) kernel, ceil(rows*ch / 256) blocks; 2: wino2s.hip's tiled layout */
 } nnl_wino_desc_t;
 int nnl_conv2d_wino_preferred(const nnl_conv_geom_t* g, int dgrad);
 int nnl_wino_filter_multi(const nnl_wino_desc_t* desc, const int32_t* block_desc, int64_t n_blocks, void* stream);

@@ -830,34 +830,49 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
 // times from a model fitted to forced-schedule sweeps (wino2.hip: w2_cost) and it is taken where that prediction beats the 1-D
 // kernel's — and only where the 1-D kernel already beats the direct one: the model was not fitted on the tiny grids the direct kernel
 // keeps (profiles/r3_wino2d_*.log: -13 ... -20 % against the 1-D kernel per ResNet-34 stage at 64 images, -3 ... -9 % at 32).
-// NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal.
+// NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal.  Mode 3 (round 4) = the spatially staged 2-D kernel (wino2s.hip: raw
+// input rows by LDS-DMA, pre-tiled U, its own event-simulated schedule model); opt-in: NNL_CONV_WINO2S=1 lets the planner take it, NNL_CONV_WINO=4 forces it.
 static int wino_mode(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
   if (!nnl_wino_ok(N, H, W, Cin, Nc, R, S, stride, pad)) return 0;
   const int e = NNL_ENV_INT("NNL_CONV_WINO", 1);
   const bool two_ok = nnl_wino2_ok(N, H, W, Cin, Nc, R, S, stride, pad);
+  const bool twos_ok = nnl_wino2s_ok(N, H, W, Cin, Nc, R, S, stride, pad);
+  if (e == 4) return twos_ok ? 3 : (two_ok ? 2 : 1);
   if (e == 3) return two_ok ? 2 : 1;
   if (e == 2) return 1;
   const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
   const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
   if (!(t_w < 0.97 * t_d)) return 0;
   const long quad_tiles = nnl_cdiv((long)N * ((H + 1) / 2) * ((W + 1) / 2), 64L) * nnl_cdiv((long)Nc, 64L);
-  if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 0) &&
-      nnl_wino2_plan_time_us(N, H, W, Cin, Nc) < 0.9 * t_w)      // 10 % predicted margin: at 32 images the two are within 5 % either way
-    return 2;
+  // the 2-D kernels (10 % predicted margin over the 1-D one: at 32 images they are within 5 % either way): the spatially staged one
+  // (wino2s.hip, mode 3) where ITS schedule model predicts less than the register-staged one's (wino2.hip, mode 2)
+  double t_2 = 1e300, t_3 = 1e300;
+  if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 0)) t_2 = nnl_wino2_plan_time_us(N, H, W, Cin, Nc);
+  // OPT-IN (NNL_CONV_WINO2S=1): in the full ResNet-34 / RetinaNet steps the staged kernel measured level with the register-staged one
+  // (ResNet-34: 96.98 vs 96.0 us per launch, step 12.83 vs 12.59 ms; RetinaNet 45.6 vs 45.2 ms: profiles/r4_wino2s_step_ab.log) although it moves
+  // 1.7x fewer bytes from the L2 and 4x fewer from beyond it (profiles/r4_wino2s_pmc_l1.txt) — DESIGN.md section 3 has the analysis
+  if (twos_ok && NNL_ENV_INT("NNL_CONV_WINO2S", 0) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 0)) t_3 = nnl_wino2s_plan_time_us(N, H, W, Cin, Nc);
+  // (same-run A/B, tools/bench_wino2s.py, profiles/r4_wino2s_ab_*.log: the staged kernel wins 12 of 16 ResNet-34 shapes at 16 - 64 images and 6 of 7
+  // RetinaNet ones by 2 - 24 %, loses the rest by 2 - 7 %; the older kernel's model reads ~15 % low against this one's)
+  if (t_3 <= 1.1 * t_2 && t_3 < 0.9 * t_w) return 3;
+  if (t_2 < 0.9 * t_w) return 2;
   return 1;
 }
 static size_t wino_mode_workspace(int mode, int N, int H, int W, int Cin, int Nc) {
-  return mode == 2 ? nnl_wino2_workspace_bytes(N, H, W, Cin, Nc) : nnl_wino_workspace_bytes(N, H, W, Cin, Nc);
+  return mode == 3 ? nnl_wino2s_workspace_bytes(N, H, W, Cin, Nc) : mode == 2 ? nnl_wino2_workspace_bytes(N, H, W, Cin, Nc) : nnl_wino_workspace_bytes(N, H, W, Cin, Nc);
 }
 static int wino_mode_launch(int mode, const WinoProblem& q, void* ws, size_t ws_bytes, int* counters, long n_counters, hipStream_t s) {
-  return mode == 2 ? nnl_wino2_launch(q, ws, ws_bytes, counters, n_counters, s) : nnl_wino_launch(q, ws, ws_bytes, counters, n_counters, s);
+  return mode == 3 ? nnl_wino2s_launch(q, ws, ws_bytes, counters, n_counters, s)
+       : mode == 2 ? nnl_wino2_launch(q, ws, ws_bytes, counters, n_counters, s) : nnl_wino_launch(q, ws, ws_bytes, counters, n_counters, s);
 }
 
-// debug / tuning: the planners' predicted launch times (us) for a 3x3 / stride 1 / pad 1 problem: out[0] direct, out[1] Winograd 1-D, out[2] 2-D
+// debug / tuning: the planners' predicted launch times (us) for a 3x3 / stride 1 / pad 1 problem: out[0] direct, out[1] Winograd 1-D, out[2] 2-D,
+// out[3] the spatially staged 2-D kernel (-1: shape not served); out must hold FOUR doubles
 extern "C" int nnl_debug_conv_plan_times(int N, int H, int W, int Cin, int Nc, double* out) {
   out[0] = plan_balance((long)N * H * W, Nc, Cin, 9).t_us;
   out[1] = nnl_wino_plan_time_us(N, H, W, Cin, Nc);
   out[2] = nnl_wino2_plan_time_us(N, H, W, Cin, Nc);
+  out[3] = nnl_wino2s_ok(N, H, W, Cin, Nc, 3, 3, 1, 1) ? nnl_wino2s_plan_time_us(N, H, W, Cin, Nc) : -1.0;
   return wino_mode(N, H, W, Cin, Nc, 3, 3, 1, 1);
 }
 
@@ -926,7 +941,7 @@ extern "C" int nnl_conv2d_fwd_pre(const float* x, const float* w, const float* b
     wq.bn_part = stats ? bn_partials : nullptr; wq.bn_pivot = bn_pivot;
     wq.u_pre = u;
     st = wino_mode_launch(wmode, wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
-    if (st == NNL_OK && stats) *bn_rows = wmode == 2 ? nnl_wino2_bn_rows(g->N, g->H, g->W) : nnl_wino_bn_rows(g->N, g->H, g->W);
+    if (st == NNL_OK && stats) *bn_rows = wmode >= 2 ? nnl_wino2_bn_rows(g->N, g->H, g->W) : nnl_wino_bn_rows(g->N, g->H, g->W);
     return st;
   }
   if (taps_ok(a_elems, b_elems, g->C, g->R * g->S)) {

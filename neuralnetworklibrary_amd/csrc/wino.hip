@@ -64,6 +64,10 @@ __global__ void wino_filter_multi_kernel(const nnl_wino_desc_t* __restrict__ des
   const nnl_wino_desc_t d = desc[block_desc[blockIdx.x]];
   const long i = ((long)blockIdx.x - d.first_block) * 256 + threadIdx.x;
   const long C = d.ch;
+  if (d.two_d == 2) {                                // the pre-tiled U of the spatially staged 2-D kernel (wino2s.hip): one block per (64 rows, 16 channels)
+    wino2s_filter_block(d.src, d.dst, (long)blockIdx.x - d.first_block, threadIdx.x, d.rows, (int)C, d.flip);
+    return;
+  }
   if (d.two_d) {                                     // U [rows][16][ch] of the 2-D kernel: one (row, channel) item per thread
     if (i < (long)d.rows * C) wino2_filter_item(d.src + (i / C) * 9 * C + i % C, d.dst + (i / C) * 16 * C + i % C, C, d.flip);
     return;

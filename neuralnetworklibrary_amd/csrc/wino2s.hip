@@ -63,27 +63,8 @@ struct Wino2sParams {
   int dbg;             // timing experiments (NNL_W2S_DBG; results invalid): bit 0 no raw traffic, bit 1 no U traffic, bit 2 no MFMA
 };
 
-// filt [Nc][3][3][C] -> U tiled [ceil(Nc/64)][4 xi][C/8][4 nu][128 slots][4]; rows >= Nc are zero.  One (k, c) item per thread.
-__device__ __forceinline__ void wino2s_filter_item(const float* __restrict__ src, float* __restrict__ dst, long k, long c, int Nc, int C, int flip) {
-  float v[16];
-  if (k < Nc) wino2_filter_vals(src + k * 9 * C + c, C, flip, v);
-  else {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = 0.f;
-  }
-  const long tn = k >> 6, kl = k & 63, b = c >> 3, hh = (c >> 2) & 1, e = c & 3, NB = C >> 3;
-  const long slot = 2 * kl + (hh ^ ((kl >> 3) & 1));
-#pragma unroll
-  for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-    for (int nu = 0; nu < 4; ++nu) dst[(((((tn * 4 + xi) * NB + b) * 4 + nu) * 128 + slot) << 2) + e] = v[xi * 4 + nu];
-}
-
-__global__ void wino2s_filter_kernel(const float* __restrict__ w, float* __restrict__ u, int Nc, int C, int flip) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // over (k padded to 64, c)
-  const long KP = (long)((Nc + 63) / 64) * 64;
-  if (i >= KP * C) return;
-  wino2s_filter_item(w, u, i / C, i % C, Nc, C, flip);
+__global__ __launch_bounds__(256) void wino2s_filter_kernel(const float* __restrict__ w, float* __restrict__ u, int Nc, int C, int flip) {
+  wino2s_filter_block(w, u, blockIdx.x, threadIdx.x, Nc, C, flip);
 }
 
 // One LDS-DMA piece: 64 lanes x 16 B from buffer offsets (voff + soff) to LDS `dst` + lane * 16.  Inline asm on purpose: hipcc's waitcnt
@@ -611,8 +592,7 @@ int nnl_wino2s_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile
   if (ws == nullptr || ws_bytes < u_floats * sizeof(float)) return nnl_set_error(NNL_ERR_WORKSPACE, "wino2s: workspace too small");
   float* u = (float*)ws;
   if (q.u_pre == nullptr) {
-    const long KC = (long)((q.Nc + 63) / 64) * 64 * q.Cin;
-    hipLaunchKernelGGL(wino2s_filter_kernel, dim3((unsigned)nnl_cdiv(KC, 256L)), dim3(256), 0, s, q.filt, u, q.Nc, q.Cin, q.flip);
+    hipLaunchKernelGGL(wino2s_filter_kernel, dim3((unsigned)(((q.Nc + 63) / 64) * ((q.Cin + 15) / 16))), dim3(256), 0, s, q.filt, u, q.Nc, q.Cin, q.flip);
     NNL_CHECK_LAUNCH();
   }
   Wino2sParams p{};

@@ -204,24 +204,25 @@ _WINO_PREF = {}                       # weight data_ptr -> [forward took the Win
 
 class _WinoBatch:
     """persistent U buffers + device descriptor tables for nnl_wino_filter_multi: items = [(key_ptr, src tensor [rows,3,3,ch], flip, mode)],
-    mode as nnl_conv2d_wino_preferred: 1 -> U [rows,12,ch] (1-D kernel), 2 -> U [rows,16,ch] (2-D kernel)"""
+    mode as nnl_conv2d_wino_preferred: 1 -> U [rows,12,ch] (1-D kernel), 2 -> U [rows,16,ch] (2-D kernel), 3 -> the pre-tiled U of the spatially
+    staged 2-D kernel (rows padded to 64)"""
 
     def __init__(self, items):
         import numpy as np
         dev = items[0][1].device
         self.key = _wino_batch_key(items)
-        total = sum(t.shape[0] * (16 if mode == 2 else 12) * t.shape[3] for _, t, _, mode in items)
+        total = sum(_wino_u_numel(t.shape[0], t.shape[3], mode) for _, t, _, mode in items)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
         desc = np.zeros(len(items), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('rows', '<i4'), ('ch', '<i4'), ('flip', '<i4'), ('first', '<i4'),
                                                     ('two_d', '<i4'), ('reserved', '<i4')]))
         block_desc, self.views, off, first = [], {}, 0, 0
         for i, (k, t, flip, mode) in enumerate(items):
             rows, ch = t.shape[0], t.shape[3]
-            n = rows * (16 if mode == 2 else 12) * ch
+            n = _wino_u_numel(rows, ch, mode)
             u = self.flat[off:off + n]
             off += n
-            nb = (rows * ch + 255) // 256 if mode == 2 else (rows * 3 * ch + 255) // 256
-            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first, 1 if mode == 2 else 0, 0)
+            nb = {3: -(-rows // 64) * -(-ch // 16), 2: (rows * ch + 255) // 256}.get(mode, (rows * 3 * ch + 255) // 256)
+            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first, {3: 2, 2: 1}.get(mode, 0), 0)
             block_desc += [i] * nb
             first += nb
             self.views[k] = u
@@ -231,6 +232,11 @@ class _WinoBatch:
 
     def run(self):
         check(lib.nnl_wino_filter_multi(ptr(self.desc), ptr(self.block_desc), self.n_blocks, stream()))
+
+
+def _wino_u_numel(rows, ch, mode):
+    "floats of the transformed filter in the layout of kernel `mode` (include/nnl.h: nnl_conv2d_wino_preferred)"
+    return {3: -(-rows // 64) * 64 * 16 * ch, 2: rows * 16 * ch}.get(mode, rows * 12 * ch)
 
 
 def _wino_batch_key(items):
@@ -442,7 +448,7 @@ class _Conv2d(torch.autograd.Function):
             part = torch.empty(((N * g.P * g.Q + 63) // 64) * K * 2, dtype=torch.float32, device=x.device)
         wmode = _wino_pref(wn.data_ptr(), 0, g)
         u = _WINO_U_FWD.get(wn.data_ptr()) if wmode else None   # the filter prepared for this step, if any — in THIS call's layout
-        if u is not None and u.numel() != K * (16 if wmode == 2 else 12) * C:
+        if u is not None and u.numel() != _wino_u_numel(K, C, wmode):
             u = None
         check(lib.nnl_conv2d_fwd_pre(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
                                      ptr(part), ptr(bn_pivot), ctypes.byref(rows) if part is not None else None, ptr(u), stream()))
@@ -516,7 +522,7 @@ class _Conv2d(torch.autograd.Function):
                 and (g.stride == 1 or (g.stride == 2 and g.R == 3 and g.S == 3 and g.pad == 1))
             wmode = _wino_pref(wn.data_ptr(), 1, g)
             u = _WINO_U_BWD.get(wn.data_ptr()) if (wmode and g.K == K) else None
-            if u is not None and u.numel() != g.C * (16 if wmode == 2 else 12) * g.K:
+            if u is not None and u.numel() != _wino_u_numel(g.C, g.K, wmode):
                 u = None
             check(lib.nnl_conv2d_dgrad_pre(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
                                            ptr(_tile_counters(dyn.device) if wsb else None), ptr(u), stream()))

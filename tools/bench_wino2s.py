@@ -13,7 +13,7 @@ sys.path.insert(0, '.')
 from neuralnetworklibrary_amd._lib import lib, ptr, stream, check
 
 
-def timed(fn, n=30, warm=5):
+def timed(fn, n=30, warm=8):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -101,6 +101,11 @@ def main():
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     counters = torch.zeros(1 << 16, dtype=torch.int32, device=dev)
+    if not args.no_time:                           # clocks / power state: the first second of work on an idle GPU runs 5-15 % slow
+        a = torch.randn(4096, 4096, device=dev)
+        for _ in range(60):
+            a = torch.tanh(a @ a * 1e-3)
+        torch.cuda.synchronize()
     for net in args.net.split(','):
         for name, Cc, K, H, W in SHAPES[net]:
             N = args.bs if net != 'checks' else 3
