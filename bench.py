@@ -295,25 +295,33 @@ def mfma_roofline(prof, n, kinds=('conv_fwd', 'conv_dgrad', 'conv_wgrad'), kerne
     flop = sum(prof[k]['work'] for k in kinds if k in prof)
     launches = sum(prof[k]['launches'] for k in kinds if k in prof)
     achieved = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    executed = sum(prof[k].get('exec', prof[k]['work']) for k in kinds if k in prof) / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel,
+            # multiplies actually ISSUED per second / peak: the Winograd kernels issue 1.5x / 2.25x fewer than the algorithmic count `frac` is
+            # quoted on (nnl_prof_collect2); this is what the matrix pipe sees, to be read beside the counter figure `mfma_busy`
+            'executed_tflops': round(executed, 2), 'executed_frac': round(executed / FP32_MFMA_PEAK_TFLOPS, 4), 'mfma_busy': None,
             'launches_per_step': launches / max(n, 1), 'avg_launch_ms': ms / max(launches, 1),
             'flop_per_launch': flop / max(launches, 1), 'kernel_ms_per_step': ms / max(n, 1), 'by_kind': by_kind(prof, n)}
 
 
-def committed_traffic(bs, sz, world):
-    """HBM-side bytes per launch of the dominant kernel family: NOT measured by this run — it comes from separate
-    `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this same command (tools/pmc_traffic.py; gfx950 corrections applied),
-    committed under profiles/.  Reported only for the configuration those passes profiled."""
-    for name in ('r3_traffic.json', 'r2_traffic.json', 'r1_traffic.json'):
-        try:
-            with open(os.path.join(ROOT, 'profiles', name)) as f:
-                t = json.load(f)
-        except Exception:
-            continue
-        if (bs, sz, world) == (t.get('bs', 64), t.get('sz', 224), t.get('gpus', 1)):
-            return round(t['traffic_bytes_per_launch']), 'profiles/%s (rocprofv3 --pmc passes of this command; a committed figure, not measured in this run)' % name
-    return None, None
+def committed_counters(bs, sz, world):
+    """HBM-side bytes per launch and MFMA-pipe busy fraction of the dominant kernel family: NOT measured by this run — they come from
+    separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` / `SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE` passes of this same command
+    (tools/pmc_traffic.py; gfx950 corrections applied), committed under profiles/ TOGETHER WITH the source stamp of the library they
+    profiled.  Reported only for the configuration those passes profiled AND only while the loaded library still carries that stamp
+    (nnl_source_stamp): after any kernel change the figures read null until the passes are re-run — they cannot go stale silently."""
+    from neuralnetworklibrary_amd import _lib
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r4_traffic.json')) as f:
+            t = json.load(f)
+    except Exception:
+        return None, None, 'no committed counter passes'
+    if (bs, sz, world) != (t.get('bs', 64), t.get('sz', 224), t.get('gpus', 1)):
+        return None, None, 'counter passes exist for another configuration only'
+    if t.get('source_stamp') != _lib.source_stamp():
+        return None, None, 'profiles/r4_traffic.json was measured on source stamp %s, this library is %s: re-run tools/gpu/r4_counters.sh' % (t.get('source_stamp'), _lib.source_stamp())
+    return round(t['traffic_bytes_per_launch']), t.get('mfma_busy'), 'profiles/r4_traffic.json (rocprofv3 --pmc passes of this command on this very build, source stamp %s; committed figures, not measured in this run)' % t['source_stamp']
 
 
 def host_info():
@@ -370,11 +378,11 @@ def _unpin_process(old):
             pass
 
 
-def cpu_baseline_resnet(bs, sz, steps=2):
-    """north_star: "next to the reference run on the node's own host cores (core count stated)".  Two legs, both printed: 16
-    threads (the CPU share of a 1-GPU slot) and 64 threads pinned to the first 64 allowed CPUs (one socket's worth) when the
-    process is allowed that many; `value` = the faster one.  The 64-thread leg is abandoned after its warm-up step if that
-    step is already >= 2x slower than the 16-thread step (an over-subscribed host: 256 threads once measured 116 s/step)."""
+def cpu_baseline_resnet(bs, sz, steps=5):
+    """north_star: "next to the reference run on the node's own host cores (core count stated)".  The oracle's ResNet-34 step is timed
+    at 16, 32 and 64 threads (pinned to the first n allowed CPUs; 16 = the CPU share of a 1-GPU slot), `steps` timed steps after a
+    warm-up each, and `value` / `cores` are the FASTEST leg's; every leg is printed.  A leg is abandoned after its warm-up step when that
+    step is already >= 2x slower than the best leg so far (an over-subscribed host: 256 threads once measured 116 s per step)."""
     from oracle import reference_math as RM, reference_nets as RN
     torch.manual_seed(0)
     net = RN.ImageClassificationNet(RN.resnet34(), 2, 512).train()
@@ -389,31 +397,36 @@ def cpu_baseline_resnet(bs, sz, steps=2):
         loss.backward()
         _sgd_adam_step(RM, params, state, 'sgd', 1e-2, 1e-4)
         loss.item()
-    threads = _cpu_threads()
-    dt = _cpu_time(step, steps)
-    legs = {str(threads): round(dt * 1e3, 1)}
-    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
-    if len(allowed) >= 48 and os.environ.get('NNL_BENCH_CPU64', '1') == '1':
-        n = min(64, len(allowed))
-        old = _pin_process(set(allowed[:n]))
+    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
+    legs, best_dt, best_n = {}, None, None
+    for n in (16, 32, 64):
+        if n > len(allowed) and n != 16:
+            continue
+        n = min(n, len(allowed))
+        old = _pin_process(set(allowed[:n])) if len(allowed) > n else None
         torch.set_num_threads(n)
         try:
             t0 = time.time()
             step()
             warm = time.time() - t0
-            if warm < 2.0 * dt:
-                dt64 = _cpu_time(step, steps)
-                legs[str(n)] = round(dt64 * 1e3, 1)
-                if dt64 < dt:
-                    dt, threads = dt64, n
-            else:
-                legs[str(n)] = 'abandoned: warm-up step %.1f s vs %.1f s per step at 16 threads' % (warm, dt)
+            if best_dt is not None and warm >= 2.0 * best_dt:
+                legs[str(n)] = 'abandoned: warm-up step %.1f s vs %.2f s per step at %d threads' % (warm, best_dt, best_n)
+                continue
+            t0 = time.time()
+            for _ in range(steps):
+                step()
+            dt = (time.time() - t0) / steps
+            legs[str(n)] = round(dt * 1e3, 1)
+            if best_dt is None or dt < best_dt:
+                best_dt, best_n = dt, n
         finally:
-            _unpin_process(old)
+            if old is not None:
+                _unpin_process(old)
             torch.set_num_threads(_cpu_threads())
-    return dict({'value': bs / dt, 'unit': 'images/s', 'cores': threads, 'kind': 'port',
-                 'sample': '%d steps of the same bs=%d %dx%d ResNet-34 train step (after 1 warm-up), torch-CPU oracle' % (steps, bs, sz, sz),
-                 'ms_per_step': dt * 1e3, 'ms_per_step_by_threads': legs}, **host_info())
+    return dict({'value': bs / best_dt, 'unit': 'images/s', 'cores': best_n, 'kind': 'port',
+                 'sample': 'fastest of %s threads, %d timed steps each (after 1 warm-up) of the same bs=%d %dx%d ResNet-34 train step, torch-CPU oracle'
+                           % ('/'.join(legs), steps, bs, sz, sz),
+                 'ms_per_step': best_dt * 1e3, 'ms_per_step_by_threads': legs}, **host_info())
 
 
 def cpu_baseline_collab(bs, steps=200):
@@ -737,9 +750,11 @@ def worker(args):
     roofline['note'] = ('achieved = ALGORITHMIC convolution flop (2 N P Q K R S C per pass, SURVEY.md 8d) / measured time: the 3x3 stride-1 '
                         'forward / dgrad launches run a fused Winograd F(2,3) kernel that issues 1.5x fewer MFMA multiplies than that count')
     roofline['conv_ms_per_step'] = roofline['kernel_ms_per_step']
-    roofline['traffic'], src = committed_traffic(args.bs, args.sz, world)
-    if src:
-        roofline['traffic_source'] = src
+    roofline['traffic'], roofline['mfma_busy'], roofline['counters_source'] = committed_counters(args.bs, args.sz, world)
+    roofline['note'] += ('; executed_frac counts the multiplies actually issued (1.5x / 2.25x fewer on the Winograd launches); mfma_busy = '
+                         'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) over the same kernels, from the committed counter passes')
+    from neuralnetworklibrary_amd import _lib as _nl
+    roofline['library_source_stamp'] = _nl.source_stamp()
     out = {
         'metric': 'ResNet-34 224x224 training throughput (Learner.train1minibatch, fwd+loss+bwd+optimizer)',
         'value': round(args.bs * world * args.steps / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'ranks_seen': ranks_seen,

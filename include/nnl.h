@@ -52,6 +52,11 @@ int nnl_prof_enable(int enable);
 /* Synchronises the recorded events and returns, per kind: launches, total ms, total algorithmic work
  * (flops or bytes as documented per op).  Arrays have NNL_PROF_KINDS entries. Resets the pool. */
 int nnl_prof_collect(int64_t* launches, double* total_ms, double* total_work);
+/* The same plus, per kind, the EXECUTED work: algorithmic work x (multiplies issued / algorithmic multiplies) of each launch — 1 for the direct
+ * kernels, 1 / 1.5 for the 1-D Winograd kernels (forward, dgrad, Winograd-domain wgrad), 1 / 2.25 for the 2-D ones.  total_exec may be NULL. */
+int nnl_prof_collect2(int64_t* launches, double* total_ms, double* total_work, double* total_exec);
+/* First 16 hex digits of the sha256 over the library's sources (csrc/ *.hip, *.h, Makefile, include/nnl.h; csrc/Makefile) it was built from. */
+const char* nnl_source_stamp(void);
 
 /* ---- K4: EmbeddingDotBias (CollabFilterNet.forward, Applications/CollabFiltering.py:196-204) ----
  * y_b = lo + (hi-lo)*sigmoid( sum_d U[x[b,0],d]*M[x[b,1],d] + bu[x[b,0]] + bi[x[b,1]] )   (has_range!=0)

@@ -37,6 +37,8 @@ SIGNATURES = {
     'nnl_reload_env': (C.c_int, []),
     'nnl_prof_enable': (C.c_int, [C.c_int]),
     'nnl_prof_collect': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
+    'nnl_prof_collect2': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
+    'nnl_source_stamp': (C.c_char_p, []),
     'nnl_embdotbias_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int, f32, f32,
                                      c_p, c_p]),
     'nnl_embdotbias_bwd_workspace_bytes': (sz, [i64]),
@@ -163,6 +165,24 @@ def prof_enable(flag=True):
 
 def prof_collect():
     n = len(PROF_KINDS)
-    a, b, c = (i64 * n)(), (f64 * n)(), (f64 * n)()
-    check(lib.nnl_prof_collect(a, b, c))
-    return {k: {'launches': int(a[i]), 'ms': float(b[i]), 'work': float(c[i])} for i, k in enumerate(PROF_KINDS)}
+    a, b, c, d = (i64 * n)(), (f64 * n)(), (f64 * n)(), (f64 * n)()
+    check(lib.nnl_prof_collect2(a, b, c, d))
+    return {k: {'launches': int(a[i]), 'ms': float(b[i]), 'work': float(c[i]), 'exec': float(d[i])} for i, k in enumerate(PROF_KINDS)}
+
+
+def source_stamp_of_tree():
+    """the stamp csrc/Makefile compiles into the library, recomputed from the sources next to this file: sha256 over the sorted csrc/*.hip and
+    csrc/*.h, the Makefile and include/nnl.h, first 16 hex digits"""
+    import glob
+    import hashlib
+    csrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'csrc')
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.h')))
+    hsh = hashlib.sha256()
+    for p in [os.path.join(csrc, n) for n in names] + [os.path.join(csrc, 'Makefile'), os.path.join(csrc, '..', '..', 'include', 'nnl.h')]:
+        with open(p, 'rb') as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
+
+
+def source_stamp():
+    return lib.nnl_source_stamp().decode()

@@ -587,7 +587,7 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
     const long fp_n = nnl_cdiv(T, gn) * pl.bm + (T < gn ? T : gn) * pl.bn;
     { const int e_nf = NNL_ENV_INT("NNL_WGRAD_NFAST", -1); q.n_fast = e_nf >= 0 ? e_nf : (fp_n < fp_m ? 1 : 0); }
   }
-  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits), block(256);
+  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits);
   const int bk32 = NNL_ENV_INT("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
   const int pipe = NNL_ENV_INT("NNL_WGRAD_PIPE", 1);                 // A/B hook: 1 = software-pipelined fragment reads
   // staging LDS: 2 buffers x BK x (BM + BN) floats per wave group (dynamic: above 64 KB the kernel needs the attribute once)
@@ -862,6 +862,7 @@ static size_t wino_mode_workspace(int mode, int N, int H, int W, int Cin, int Nc
   return mode == 3 ? nnl_wino2s_workspace_bytes(N, H, W, Cin, Nc) : mode == 2 ? nnl_wino2_workspace_bytes(N, H, W, Cin, Nc) : nnl_wino_workspace_bytes(N, H, W, Cin, Nc);
 }
 static int wino_mode_launch(int mode, const WinoProblem& q, void* ws, size_t ws_bytes, int* counters, long n_counters, hipStream_t s) {
+  nnl_prof_exec_frac(mode >= 2 ? 1.0 / 2.25 : 1.0 / 1.5);                  // multiplies issued per algorithmic multiply (bench.py: roofline.executed_frac)
   return mode == 3 ? nnl_wino2s_launch(q, ws, ws_bytes, counters, n_counters, s)
        : mode == 2 ? nnl_wino2_launch(q, ws, ws_bytes, counters, n_counters, s) : nnl_wino_launch(q, ws, ws_bytes, counters, n_counters, s);
 }
@@ -1159,6 +1160,7 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
   NnlProfScope prof(NNL_PROF_CONV_WGRAD, s, 2.0 * p.Kp * (double)p.Mc * p.Nc);
   if (wgrad_wino_ok(g)) {                                   // Winograd-domain weight gradient (igemm_wgrad.h, WINO) + the fold-back reduce
     const WgradPlan wp = plan_wgrad_wino(g);
+    nnl_prof_exec_frac(1.0 / 1.5);
     int st2 = launch_wgrad_wino(dy, x, (float*)workspace, g, wp, s);
     if (st2) return st2;
     const long n4 = (long)g->K * 3 * (g->C / 4);

@@ -43,6 +43,7 @@ int nnl_env_generation();          // bumped by nnl_reload_env(): caches of env-
 // optional per-launch profiling with HIP events on the launch stream (bench.py roofline leg)
 void nnl_prof_begin(int kind, hipStream_t s);
 void nnl_prof_end(int kind, hipStream_t s, double work);
+void nnl_prof_exec_frac(double f);   // the launch in flight executes f x its algorithmic multiplies (Winograd kernels: 1 / 1.5, 1 / 2.25)
 
 struct NnlProfScope {
   int kind; hipStream_t s; double work;

@@ -30,15 +30,18 @@ int nnl_env_cached(const char* name, int dflt, int* value, int* generation) {
 extern "C" int nnl_reload_env(void) { ++g_env_generation; return NNL_OK; }
 int nnl_env_generation() { return g_env_generation; }
 extern "C" const char* nnl_last_error(void) { return g_err; }
+#include "stamp.inc"
+extern "C" const char* nnl_source_stamp(void) { return NNL_SOURCE_STAMP; }
 
 // ---- profiling: a bounded pool of event pairs, recorded on the stream each kernel is launched on ----
 namespace {
-struct ProfRec { int kind; hipEvent_t a, b; double work; };
+struct ProfRec { int kind; hipEvent_t a, b; double work, exec; };
 std::mutex g_mu;
 bool g_enabled = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_free;
 thread_local hipEvent_t g_open_a = nullptr;
+thread_local double g_exec_frac = 1.0;      // executed / algorithmic multiplies of the launch in flight (Winograd kernels < 1)
 const size_t kMaxRecs = 200000;
 
 hipEvent_t get_event() {
@@ -54,6 +57,7 @@ void nnl_prof_begin(int kind, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (g_recs.size() >= kMaxRecs) { g_open_a = nullptr; return; }
   g_open_a = get_event();
+  g_exec_frac = 1.0;
   if (g_open_a) (void)hipEventRecord(g_open_a, s);
 }
 
@@ -63,9 +67,11 @@ void nnl_prof_end(int kind, hipStream_t s, double work) {
   hipEvent_t b = get_event();
   if (!b) { g_free.push_back(g_open_a); g_open_a = nullptr; return; }
   (void)hipEventRecord(b, s);
-  g_recs.push_back({kind, g_open_a, b, work});
+  g_recs.push_back({kind, g_open_a, b, work, work * g_exec_frac});
   g_open_a = nullptr;
 }
+
+void nnl_prof_exec_frac(double f) { g_exec_frac = f; }
 
 extern "C" int nnl_prof_enable(int enable) {
   std::lock_guard<std::mutex> lk(g_mu);
@@ -73,15 +79,18 @@ extern "C" int nnl_prof_enable(int enable) {
   return NNL_OK;
 }
 
-extern "C" int nnl_prof_collect(int64_t* launches, double* total_ms, double* total_work) {
+extern "C" int nnl_prof_collect(int64_t* launches, double* total_ms, double* total_work) { return nnl_prof_collect2(launches, total_ms, total_work, nullptr); }
+
+extern "C" int nnl_prof_collect2(int64_t* launches, double* total_ms, double* total_work, double* total_exec) {
   std::lock_guard<std::mutex> lk(g_mu);
-  for (int k = 0; k < NNL_PROF_KINDS; ++k) { launches[k] = 0; total_ms[k] = 0; total_work[k] = 0; }
+  for (int k = 0; k < NNL_PROF_KINDS; ++k) { launches[k] = 0; total_ms[k] = 0; total_work[k] = 0; if (total_exec) total_exec[k] = 0; }
   for (auto& r : g_recs) {
     hipError_t e = hipEventSynchronize(r.b);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
     if (e == hipSuccess && r.kind >= 0 && r.kind < NNL_PROF_KINDS) {
       launches[r.kind] += 1; total_ms[r.kind] += ms; total_work[r.kind] += r.work;
+      if (total_exec) total_exec[r.kind] += r.exec;
     }
     g_free.push_back(r.a); g_free.push_back(r.b);
   }

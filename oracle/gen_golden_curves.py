@@ -187,5 +187,76 @@ def g15_retinanet_bs16(steps=10):
 GROUPS = {'g13b': g13b_resnet34_curve, 'g14': g14_lm_curve, 'g15': g15_retinanet_bs16}
 
 if __name__ == '__main__':
-    for name in (sys.argv[1:] or list(GROUPS)):
+    for name in ([a for a in sys.argv[1:] if a in GROUPS] if sys.argv[1:] else list(GROUPS)):
+        GROUPS[name]()
+
+
+def _g13c_net(dtype):
+    RN = R['Applications.VisionModels.retinanet']
+    V = R['Applications.Vision']
+    N, S = 64, 224
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
+    arch = RN.RetinaNet(2, RN.BasicBlock, [3, 4, 6, 3])
+    net = V.ImageClassificationNet(D, arch, head=[[512], [0., 0.]], cutpoint=8, splits=[6])
+    synth.fill_reference_init_(net, seed=13)
+    synth.tame_residual_branches_(net)                          # frozen BatchNorm = no renormalisation: keep the 16 residual sums O(1)
+    net = net.to(dtype)
+    d = D(); d.train_dl = [(None, torch.zeros(N))]; d.val_dl = d.train_dl
+    learner = Learner('/tmp/nnl_golden_g13c', d, net, optimizer='SGD_Mom')
+    learner.bn_freeze('all')                                   # Learner.py:248-264: BatchNorm parameters out of the optimizer ...
+    learner.init_optimizer(wd=1e-4)
+    net.train()
+    for m in net.modules():                                    # ... and, as train_gen_sched does (Learner.py:589-591), running statistics in the forward
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.training = False
+    return net, learner, N, S
+
+
+def g13c_probe():
+    "gradient norms per layer group of the frozen-BatchNorm network at its initial weights (chooses G13c's learning rates)"
+    net, learner, N, S = _g13c_net(torch.float32)
+    x, y = synth.curve_batch_images(N, S, 1400)
+    loss = torch.nn.functional.cross_entropy(net(x), y)
+    loss.backward()
+    print('loss', loss.item())
+    for gi, grp in enumerate(net.layer_groups):
+        g2 = sum(float(p.grad.double().pow(2).sum()) for p in grp.parameters() if p.grad is not None)
+        print('group', gi, 'grad norm', g2 ** 0.5, flush=True)
+
+
+def g13c_resnet34_frozen_bn_curve(steps=20):
+    """G13c (VERDICT r3 next #4a): a 20-step curve at BASELINE configs[1]'s size that is SENSITIVE to the convolution weight gradients —
+    ResNet-34 + default head, 224x224, bs 64, SGD momentum 0.9, wd 1e-4, `Learner.bn_freeze('all')` with the BatchNorm layers on their
+    running statistics as `train_gen_sched` runs them (Learner.py:248-264, 589-591: no batch-statistics coupling, well conditioned —
+    DESIGN.md section 4, conditioning note), 20 distinct learnable batches (synth.curve_batch_images tags 1400+i).  The body learning
+    rates are chosen so that the reference's own HEAD-ONLY run (body lr 0) leaves the full curve by >= 20 % while its fp32 and fp64 runs
+    stay within 3e-4 of each other on every step — both asserted here; a ~5 % error in every body weight gradient moves this curve by
+    ~1e-2, ten times the GPU test's tolerance (G13b moves by 6e-4 for the same error)."""
+    lr = [float(v) for v in os.environ.get('G13C_LR', '3e-6,1e-5,3e-5').split(',')]
+    out = {'N': 64, 'S': 224, 'steps': steps, 'lr': np.array(lr), 'wd': 1e-4, 'init_seed': 13}
+    for tag, dtype, lrs in [('f32', torch.float32, lr), ('f32.headonly', torch.float32, [0., 0., lr[2]]), ('f64', torch.float64, lr)]:
+        net, learner, N, S = _g13c_net(dtype)
+        losses = []
+        for i in range(steps):
+            x, y = synth.curve_batch_images(N, S, 1400 + i)
+            losses.append(learner.train1minibatch(x.to(dtype), y, lrs))
+            print(tag, i, losses[-1], flush=True)
+        out['losses.' + tag] = np.array(losses, dtype=np.float64)
+        out['after.abs_sums.' + tag] = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+        if tag == 'f32':
+            out['param_names'] = np.array([n for n, _ in net.named_parameters()])
+    share = (np.abs(out['losses.f32.headonly'] - out['losses.f32']) / out['losses.f32']).max()
+    print('body share of the curve: max rel |headonly - f32| = %.2e' % share)
+    assert share >= 0.2, 'the curve is not sensitive enough to the body gradients'
+    _check_sep(out['losses.f32'], out['losses.f64'], 'g13c')
+    save('g13c_resnet34_frozen_bn_curve', **out)
+
+
+GROUPS.update({'g13c': g13c_resnet34_frozen_bn_curve, 'g13c_probe': g13c_probe})
+
+if __name__ == '__main__' and 'GROUPS_LATE' not in globals():
+    GROUPS_LATE = True
+    for name in [a for a in sys.argv[1:] if a in ('g13c', 'g13c_probe', 'g16')]:
         GROUPS[name]()

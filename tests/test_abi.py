@@ -26,6 +26,15 @@ def test_header_symbols_exported_and_bound():
     assert not extra, f'exported but not declared in nnl.h: {extra}'
 
 
+def test_loaded_library_is_built_from_this_tree():
+    """The loaded libnnl_hip.so carries the stamp of the sources it was built from (csrc/Makefile: sha256 over csrc/*.hip, *.h, the
+    Makefile and include/nnl.h); it must equal the hash of the sources in THIS tree — a stale prebuilt library fails here, on the
+    build box and on the GPU box alike (the sources travel with the snapshot)."""
+    from neuralnetworklibrary_amd import _lib
+    built, tree = _lib.source_stamp(), _lib.source_stamp_of_tree()
+    assert len(built) == 16 and built == tree, 'libnnl_hip.so built from other sources (stamp %s, tree %s): run __graft_entry__.build()' % (built, tree)
+
+
 def test_version_and_error_string():
     from neuralnetworklibrary_amd import _lib
     assert _lib.lib.nnl_version() >= 100
