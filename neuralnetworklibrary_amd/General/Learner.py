@@ -159,8 +159,8 @@ class _GraphedStep:
         """Non-DP: the whole step (forward, loss, backward, fused optimizer) is one graph.  Data parallel: the graph holds forward,
         loss and backward — the gradient hooks' copies into the all-reduce buckets are captured with it — and each replay is
         followed, eagerly, by the bucket all-reduces (RCCL is not captured) and the fused optimizer launch.  The collectives then
-        start after the whole backward instead of overlapping it, but at the small per-GPU batches of strong scaling the step is
-        launch-bound (ResNet-34 at 8 images: 8.4 ms eager, 4.7 ms replayed), which is what the graph removes."""
+        used to start after the whole backward; since round 4 the captured backward carries one signal kernel per bucket and the
+        collectives start behind per-bucket wait kernels on a side stream, i.e. in the middle of the replay (dist.py: reduce_overlapped)."""
         opt, gs = learner.optimizer, learner.grad_sync
         dp = gs is not None
         if self.graph is None:
@@ -175,7 +175,8 @@ class _GraphedStep:
             opt.opt.zero_grad()
             if dp:
                 gs.begin(1.0)
-                gs.capturing = True                   # hooks fill the buckets but launch no collective
+                gs.capturing = True                   # hooks fill the buckets (+ per-bucket signal kernels) but launch no collective
+                gs.prepare_overlap()                  # device words + side stream of the replay overlap (allocated OUTSIDE the capture)
             else:
                 opt.prepare_capture()
             torch.cuda.synchronize()
@@ -184,6 +185,8 @@ class _GraphedStep:
                 # data parallel: RCCL's watchdog thread polls the events of earlier collectives from ANOTHER thread; in the default
                 # "global" capture mode that invalidates the capture ("operation not permitted when stream is capturing")
                 with torch.cuda.graph(graph, capture_error_mode='thread_local' if dp else 'global'):   # records; nothing executes until replay()
+                    if dp:
+                        gs.capture_begin()            # the replay counter's bump: the first node of the graph
                     y_pred = learner.predict1minibatch(self.x)
                     self.loss = learner.loss_func(y_pred, self.y)
                     learner._backward(self.loss)
@@ -191,6 +194,7 @@ class _GraphedStep:
                         opt.step()
             finally:
                 if dp:
+                    gs.capture_end()
                     gs.capturing, gs._active = False, False
             self.graph = graph
             self.opt_capture = None if dp else opt.captured()
@@ -201,7 +205,9 @@ class _GraphedStep:
                 opt.replay_step(self.opt_capture)
         self.graph.replay()
         if dp:
-            gs.reduce_all(learner._dp_weight)
+            # the replay is only ENQUEUED here: the per-bucket wait kernels + all-reduces go to a side stream now and run under the rest of
+            # the replayed backward (dist.GradSync.reduce_overlapped; CPU / NNL_DIST_REPLAY_OVERLAP=0: all buckets after the replay)
+            gs.reduce_overlapped(learner._dp_weight)
             opt.step()
         return self.loss.item()
 
@@ -720,6 +726,8 @@ class Learner(object):
                     self._print_batch(j, debiased, loss, metrics, x_batch, y_batch, time.time() - tb)
 
             _raise_if_index_error()                       # bad ids met by this epoch's gathers (checked once, not per step)
+            if self.grad_sync is not None:
+                self.grad_sync.raise_if_overlap_error()   # a bucket wait kernel of the replayed data-parallel step timed out
             train_loss = debiased if self.use_moving_avg else self.evaluate('train')
 
             res = self.evaluate('val', metrics)

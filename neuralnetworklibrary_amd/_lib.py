@@ -39,6 +39,9 @@ SIGNATURES = {
     'nnl_prof_collect': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64)]),
     'nnl_prof_collect2': (C.c_int, [C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
     'nnl_source_stamp': (C.c_char_p, []),
+    'nnl_dp_bump': (C.c_int, [c_p, c_p]),
+    'nnl_dp_signal': (C.c_int, [c_p, c_p, c_p]),
+    'nnl_dp_wait': (C.c_int, [c_p, i32, i64, c_p, c_p]),
     'nnl_embdotbias_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, C.c_int, f32, f32,
                                      c_p, c_p]),
     'nnl_embdotbias_bwd_workspace_bytes': (sz, [i64]),

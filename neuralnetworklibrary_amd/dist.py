@@ -136,6 +136,8 @@ class GradSync:
                 self._use_counts.append(p._nnl_uses)
         self._active = False
         self.capturing = False                          # Learner.use_graphs under DP: hooks fill the buckets, collectives run after the replay
+        self.overlap = None                             # _ReplayOverlap once a step has been captured with per-bucket signals (GPU only)
+        self.overlap_launches = 0                       # collectives that were enqueued behind a wait kernel (diagnostics)
         self.weight = 1.0
         self.direct_writes, self.steps = 0, 0           # gradients that arrived in place / backward passes (diagnostics)
 
@@ -180,12 +182,83 @@ class GradSync:
         b.ready[pi] = True
         b.pending -= 1
         if self.capturing:
+            # hipGraph capture of forward + backward: no collective is captured.  On the GPU the complete buckets at the head of the
+            # queue get their flag words set and a SIGNAL kernel (csrc/runtime.hip: nnl_dp_signal) right here — i.e. at the point of
+            # the captured backward where their last gradient has been written — so that reduce_overlapped() can start bucket k's
+            # all-reduce in the MIDDLE of each replay (strictly in bucket order, as the eager path)
+            if self.overlap is not None:
+                while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+                    bk = self.buckets[self._next]
+                    bk.flags.fill_(1.0)
+                    self.overlap.signal(self._next)
+                    self._next += 1
             return
         # collectives are issued strictly in bucket order on every rank (a rank whose data did not reach some parameter must
         # not pair its bucket k with another rank's bucket j): launch the complete buckets at the head of the queue
         while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
             self._launch(self.buckets[self._next])
             self._next += 1
+
+    def prepare_overlap(self):
+        """BEFORE the capture of a data-parallel step (allocations and stream creation must not be captured): the device words and side
+        stream of the replay-overlap protocol.  Not available on CPU tensors (the gloo tests) or with NNL_DIST_REPLAY_OVERLAP=0: then
+        reduce_all() is the replay path."""
+        dev = self.buckets[0].flat.device if self.buckets else None
+        if dev is None or dev.type != 'cuda' or os.environ.get('NNL_DIST_REPLAY_OVERLAP', '1') == '0':
+            self.overlap = None
+        else:
+            self.overlap = _ReplayOverlap(len(self.buckets), dev)
+        self._next = 0
+
+    def capture_begin(self):
+        "first thing INSIDE the capture (Learner._GraphedStep): the replay counter's bump"
+        if self.overlap is not None:
+            self.overlap.bump()
+
+    def capture_end(self):
+        "which buckets got a signal in the captured backward (the others — parameters without a gradient — are reduced after the replay)"
+        if self.overlap is not None:
+            self.overlap.signalled = self._next
+        self._next = 0
+
+    def reduce_overlapped(self, weight=1.0):
+        """After a captured forward + backward has been ENQUEUED (graph.replay() returned): for every bucket, in order, a wait kernel on the
+        side stream (until the replay's signal for that bucket) followed by its all-reduce — the collectives of the early buckets run
+        under the rest of the replayed backward; buckets that completed without a signal wait for the whole replay.  Then finish()."""
+        ov = self.overlap
+        if ov is None:
+            return self.reduce_all(weight)
+        self._active, self.weight, self._next = True, float(weight), 0
+        ov.replays += 1
+        main = torch.cuda.current_stream()
+        for k, b in enumerate(self.buckets):
+            b.pending, b.ready, b.handle, b.averaged = 0, [True] * len(b.params), None, False
+            if k < ov.signalled:
+                ov.wait(k)                                # enqueued on ov.side
+            else:
+                ov.side.wait_stream(main)                 # no signal in the capture: after the whole replay
+            with torch.cuda.stream(ov.side):
+                if k >= ov.signalled:
+                    b.flags.fill_(1.0)
+                self._launch_filled(b)
+            self.overlap_launches += int(k < ov.signalled)
+        self._next = len(self.buckets)
+        main.wait_stream(ov.side)                         # (the averaged buckets are consumed on the main stream)
+        self.finish()
+
+    def _launch_filled(self, b):
+        "the collective of a bucket whose flag words are already set (replay path)"
+        if self.weight != 1.0:
+            b.flat[:b.numel].mul_(self.weight)
+        if world_size() > 1 or (dist.is_initialized() and _FORCE_ALLREDUCE):
+            b.averaged = dist.get_backend(self.group) == 'nccl'
+            op = dist.ReduceOp.AVG if b.averaged else dist.ReduceOp.SUM
+            b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+
+    def raise_if_overlap_error(self):
+        "a wait kernel of the replay path ran into its poll bound (the signal never came): surfaced at the same points as index errors"
+        if self.overlap is not None and int(self.overlap.err.item()) != 0:
+            raise RuntimeError('data-parallel replay: a bucket wait kernel timed out (no signal from the captured backward)')
 
     def reduce_all(self, weight=1.0):
         """After the replay of a captured forward + backward (which filled every bucket): all-reduce all buckets now, in order."""
@@ -228,6 +301,32 @@ class GradSync:
                     p.grad = v
                 else:
                     p.grad = None
+
+
+class _ReplayOverlap:
+    """Device words and the side stream of the replay-overlap protocol (csrc/runtime.hip: nnl_dp_bump / _signal / _wait): step[0] counts
+    replays (bumped by the graph itself), flag[k] = the replay that has completed bucket k, err != 0 after a wait kernel's time-out."""
+
+    def __init__(self, n_buckets, device):
+        from . import _lib
+        self._lib = _lib
+        self.words = torch.zeros(n_buckets + 2, dtype=torch.int32, device=device)      # [step, err, flag_0 ... flag_{n-1}]
+        self.step, self.err, self.flags = self.words[0:1], self.words[1:2], self.words[2:]
+        self.side = torch.cuda.Stream(device=device)
+        self.replays, self.signalled = 0, 0
+        self.max_polls = int(os.environ.get('NNL_DIST_WAIT_POLLS', 4000000))          # x ~0.3 us per poll: ~1 s
+
+    def _s(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def bump(self):
+        self._lib.check(self._lib.lib.nnl_dp_bump(self.step.data_ptr(), self._s()))
+
+    def signal(self, k):
+        self._lib.check(self._lib.lib.nnl_dp_signal(self.flags[k:k + 1].data_ptr(), self.step.data_ptr(), self._s()))
+
+    def wait(self, k):
+        self._lib.check(self._lib.lib.nnl_dp_wait(self.flags[k:k + 1].data_ptr(), self.replays, self.max_polls, self.err.data_ptr(), self.side.cuda_stream))
 
 
 class ShardedBatches:

@@ -234,7 +234,7 @@ def g13c_resnet34_frozen_bn_curve(steps=20):
     rates are chosen so that the reference's own HEAD-ONLY run (body lr 0) leaves the full curve by >= 20 % while its fp32 and fp64 runs
     stay within 3e-4 of each other on every step — both asserted here; a ~5 % error in every body weight gradient moves this curve by
     ~1e-2, ten times the GPU test's tolerance (G13b moves by 6e-4 for the same error)."""
-    lr = [float(v) for v in os.environ.get('G13C_LR', '3e-6,1e-5,3e-5').split(',')]
+    lr = [float(v) for v in os.environ.get('G13C_LR', '1e-4,2e-5,1.2e-5').split(',')]
     out = {'N': 64, 'S': 224, 'steps': steps, 'lr': np.array(lr), 'wd': 1e-4, 'init_seed': 13}
     for tag, dtype, lrs in [('f32', torch.float32, lr), ('f32.headonly', torch.float32, [0., 0., lr[2]]), ('f64', torch.float64, lr)]:
         net, learner, N, S = _g13c_net(dtype)
@@ -258,5 +258,51 @@ GROUPS.update({'g13c': g13c_resnet34_frozen_bn_curve, 'g13c_probe': g13c_probe})
 
 if __name__ == '__main__' and 'GROUPS_LATE' not in globals():
     GROUPS_LATE = True
-    for name in [a for a in sys.argv[1:] if a in ('g13c', 'g13c_probe', 'g16')]:
+    for name in [a for a in sys.argv[1:] if a in ('g13c', 'g13c_probe')]:
         GROUPS[name]()
+
+
+ROSSMANN_CARDS, rossmann_batch = synth.ROSSMANN_CARDS, synth.rossmann_batch
+
+
+def g16_rossmann_curve(steps=20):
+    """G16 (VERDICT r3 next #4b): 20 consecutive `Learner.train1minibatch` steps of the REFERENCE at BASELINE configs[2]'s real shape —
+    StructuredDataNet (StructuredData.py:1038-1084) with the 32 Rossmann cardinalities of SURVEY 8d (default embedding sizes -> 189 + 14
+    = 203 inputs), fc [1000, 500, 1], output range [5, 12], bs 1024, Adam, lr [5e-4, 5e-4], wd 1e-3, every dropout 0, BatchNorm1d in
+    training mode, nn.Embedding(max_norm = 1.5) renormalising the looked-up rows in place on every forward; 20 distinct learnable batches
+    (rossmann_batch).  fp32 and fp64 runs of the reference must stay within 3e-4 (asserted)."""
+    SD = R['Applications.StructuredData']
+    bs, n_cont = 1024, 14
+    lr = [5e-4, 5e-4]                # (at 1e-3 the reference's own fp32 / fp64 runs separate by 4.1e-4 at step 19)
+    labels = [{i: i for i in range(c)} for c in ROSSMANN_CARDS]
+    out = {'bs': bs, 'n_cont': n_cont, 'steps': steps, 'lr': np.array(lr), 'wd': 1e-3, 'init_seed': 16, 'cards': np.array(ROSSMANN_CARDS)}
+    for tag, dtype in [('f32', torch.float32), ('f64', torch.float64)]:
+        net = SD.StructuredDataNet('cont', len(ROSSMANN_CARDS), n_cont, labels, [1000, 500, 1], output_range=[5, 12])
+        synth.fill_module_(net, seed=16)
+        net = net.to(dtype)
+        data = FakeData([(None, torch.zeros(bs))], [(None, torch.zeros(bs))], bs, 'cont')
+        learner = Learner('/tmp/nnl_golden_g16', data, net, optimizer='Adam')
+        learner.init_optimizer(wd=1e-3)
+        net.train()
+        losses = []
+        for i in range(steps):
+            xcat, xcont, y = rossmann_batch(bs, n_cont, i)
+            losses.append(learner.train1minibatch([torch.from_numpy(xcat), torch.from_numpy(xcont).to(dtype)], torch.from_numpy(y).to(dtype), lr))
+        print(tag, np.array2string(np.array(losses), precision=5), flush=True)
+        out['losses.' + tag] = np.array(losses, dtype=np.float64)
+        out['after.abs_sums.' + tag] = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()], dtype=np.float64)
+        if tag == 'f32':
+            out['param_names'] = np.array([n for n, _ in net.named_parameters()])
+            out['emb_dims'] = np.array([e.emb.weight.shape[1] for e in net.embeddings])
+            net.eval()
+            xcat, xcont, y = rossmann_batch(bs, n_cont, 0)
+            out['eval_pred0.f32'] = A(net(torch.from_numpy(xcat), torch.from_numpy(xcont)))[:64]
+    _check_sep(out['losses.f32'], out['losses.f64'], 'g16')
+    save('g16_rossmann_curve', **out)
+
+
+GROUPS['g16'] = g16_rossmann_curve
+from gen_golden import FakeData  # noqa: E402
+
+if __name__ == '__main__' and 'g16' in sys.argv[1:]:
+    g16_rossmann_curve()

@@ -158,3 +158,17 @@ def tame_residual_branches_(net, gamma=0.3):
                 n += 1
     assert n == 16, n
     return net
+
+
+ROSSMANN_CARDS = [1116, 5, 4, 13, 53, 13, 4, 8, 32, 23, 27, 24, 28, 9, 5, 5] + [10] * 16      # SURVEY.md 8d config 3 (as bench.py)
+
+
+def rossmann_batch(bs, n_cont, tag):
+    """one LEARNABLE Rossmann-shaped minibatch (fixture G16; the tests regenerate it from the tag): categorical columns ~ U{0..c-1},
+    continuous ~ N(0,1), target = 8.5 + a fixed linear function of three continuous columns and of the parity of two categorical
+    ones + noise, inside the output range [5, 12]"""
+    rs = np.random.RandomState(160000 + tag)
+    xcat = np.stack([rs.randint(0, c, size=bs) for c in ROSSMANN_CARDS], 1).astype(np.int64)
+    xcont = rs.standard_normal((bs, n_cont)).astype(np.float32)
+    y = 8.5 + 0.8 * xcont[:, 0] - 0.5 * xcont[:, 3] + 0.3 * xcont[:, 7] + 0.6 * (xcat[:, 1] % 2) - 0.4 * (xcat[:, 5] % 2) + 0.1 * rs.standard_normal(bs)
+    return xcat, xcont, np.clip(y, 5.2, 11.8).astype(np.float32)

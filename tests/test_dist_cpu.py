@@ -295,3 +295,80 @@ def test_lm_stream_sharding_64_over_8_keeps_the_carried_state_rank_local():
         np.testing.assert_allclose(w, w1, rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(h, h1[:, 8 * r:8 * r + 8], rtol=2e-5, atol=2e-6)
         np.testing.assert_allclose(c, c1[:, 8 * r:8 * r + 8], rtol=2e-5, atol=2e-6)
+
+
+# ---- the replay path of Learner.use_graphs() under data parallelism (round 4: per-bucket segments) -------------------------------------
+def _replay_protocol(rank, world, port, q):
+    """Each rank runs the SAME three data-parallel steps twice from the same weights: (a) eagerly — the hooks launch bucket k's all-reduce
+    as soon as its gradients are complete, in the middle of backward — and (b) through the protocol of a captured step: hooks armed in
+    `capturing` mode during backward (buckets are filled, bucket completions are recorded in order, NO collective is issued), then
+    `reduce_overlapped()` issues the collectives bucket by bucket in bucket order (on the GPU each behind its wait kernel; on CPU tensors
+    the device-side signals do not exist and the collectives follow the backward).  Both must leave bitwise the same averaged gradients
+    and weights, and every rank must have issued the same number of collectives in the same order."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    torch.set_num_threads(1)
+    nd.init_from_env('gloo')
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 6, generator=g) for _ in range(3)]
+    ys = [torch.randn(8, generator=g) for _ in range(3)]
+    a, z = rank * 4, rank * 4 + 4
+    results = []
+    for mode in ('eager', 'replay'):
+        net = _model(seed=1)
+        gs = nd.GradSync(net, bucket_mb=0.0001)
+        assert len(gs.buckets) >= 3
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        order = []
+        launch = gs._launch
+        gs._launch = lambda b, _l=launch: (order.append(gs.buckets.index(b)), _l(b))[1]
+        launch_f = gs._launch_filled
+        gs._launch_filled = lambda b, _l=launch_f: (order.append(gs.buckets.index(b)), _l(b))[1]
+        for x, y in zip(xs, ys):
+            opt.zero_grad(set_to_none=True)
+            loss = ((net(x[a:z]) - y[a:z]) ** 2).mean()
+            if mode == 'eager':
+                gs.begin(1.0)
+                loss.backward()
+                gs.finish()
+            else:
+                gs.begin(1.0)
+                gs.capturing = True
+                gs.prepare_overlap()                       # CPU tensors: no device-side signals (overlap is None)
+                gs.capture_begin()
+                loss.backward()                            # "capture": buckets filled, nothing sent
+                gs.capture_end()
+                gs.capturing, gs._active = False, False
+                assert order == [] or len(order) % len(gs.buckets) == 0
+                gs.reduce_overlapped(1.0)                  # "after the replay": collectives in bucket order
+            opt.step()
+        assert order == list(range(len(gs.buckets))) * 3, order
+        results.append(torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [p.grad.reshape(-1) for p in net.parameters()]))
+    assert torch.equal(results[0], results[1]), 'replay protocol != eager data parallelism'
+    # and both equal the single-process gradient step on the concatenated batch
+    net = _model(seed=1)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    for x, y in zip(xs, ys):
+        opt.zero_grad(set_to_none=True)
+        ((net(x) - y) ** 2).mean().backward()
+        opt.step()
+    ref = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(results[1][:ref.numel()], ref, rtol=1e-5, atol=1e-6)
+    if rank == 0:
+        q.put('ok')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replay_protocol_collectives_in_bucket_order_equal_eager_dp():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replay_protocol, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=180) == 'ok'
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0

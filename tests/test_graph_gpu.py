@@ -152,27 +152,42 @@ def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
             sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
             train_dl = val_dl = batches
 
-        def run(dp, graphs):
+        def run(dp, graphs, overlap=True):
+            os.environ['NNL_DIST_REPLAY_OVERLAP'] = '1' if overlap else '0'
             torch.manual_seed(0)
             net = V.ImageClassificationNet(D, V.models.resnet18(), head=[[64], [0., 0.]])
             learner = Learner('/tmp/nnl_graph_test', D, net, optimizer='SGD_Mom')
             learner.init_optimizer(wd=1e-4)
             if dp:
-                learner.distribute(equal_shards=True)
+                learner.distribute(bucket_mb=8.0, equal_shards=True)         # resnet18: 45 MB of gradients -> 6 buckets
+                assert len(learner.grad_sync.buckets) >= 5
             if graphs:
                 learner.use_graphs(True, warmup=2)
             net.train()
             losses = [learner.train1minibatch(*batches[i % 3], [1e-3, 2e-3, 5e-3], mom_batch=0.9) for i in range(9)]
             ng = sum(gs.graph is not None for gs in learner._graphs.values())
-            return np.array(losses), [p.detach().cpu().numpy().copy() for p in net.parameters()], ng
-        l0, p0, _ = run(False, False)
-        l1, p1, n1 = run(True, False)
-        l2, p2, n2 = run(True, True)
-        assert n1 == 0 and n2 == 1
+            gsync = learner.grad_sync
+            if gsync is not None:
+                gsync.raise_if_overlap_error()
+            return np.array(losses), [p.detach().cpu().numpy().copy() for p in net.parameters()], ng, gsync
+        l0, p0, _, _ = run(False, False)
+        l1, p1, n1, _ = run(True, False)
+        l2, p2, n2, g2 = run(True, True)
+        l3, p3, n3, g3 = run(True, True, overlap=False)
+        os.environ.pop('NNL_DIST_REPLAY_OVERLAP', None)
+        assert n1 == 0 and n2 == 1 and n3 == 1
+        # round 4: the captured backward carries one signal kernel per bucket; every replay's collectives were enqueued behind wait kernels
+        # on the side stream (6 replays x all buckets), none timed out; with the overlap switched off they follow the whole replay
+        assert g2.overlap is not None and g2.overlap.signalled == len(g2.buckets) and g2.overlap_launches == 6 * len(g2.buckets)
+        assert int(g2.overlap.flags.min().item()) == g2.overlap.replays == 6 and int(g2.overlap.step.item()) == 6
+        assert g3.overlap is None and g3.overlap_launches == 0
         assert_close(l1, l0, 1e-5, 1e-6, 'eager DP vs eager')
-        assert_close(l2, l1, 1e-5, 1e-6, 'graph DP vs eager DP')
+        assert_close(l2, l1, 1e-5, 1e-6, 'graph DP (overlapped collectives) vs eager DP')
+        assert_close(l3, l1, 1e-5, 1e-6, 'graph DP (collectives after the replay) vs eager DP')
         for a, b in zip(p2, p1):
             assert_close(a, b, 1e-4, 1e-6, 'params')
+        for a, b in zip(p3, p2):
+            assert np.array_equal(a, b), 'overlapped and non-overlapped replays must be bitwise identical'
     finally:
         nd._FORCE_ALLREDUCE = forced
         if created:

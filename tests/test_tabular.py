@@ -177,3 +177,81 @@ def test_scaled_sigmoid_output_activation():
     out.backward(dy.to('cuda'))
     assert_close(out, ref.float(), 1e-6, 1e-6, 'y')
     assert_close(xd.grad, x64.grad.float(), 2e-5, 1e-6, 'dx')
+
+
+# ---- G16: 20 reference train1minibatch steps at BASELINE config 3's REAL shape (VERDICT r3 next #4b) --------------------------------
+def _g16_batches(g):
+    bs, n_cont = int(g['bs']), int(g['n_cont'])
+    out = []
+    for i in range(int(g['steps'])):
+        xcat, xcont, y = synth.rossmann_batch(bs, n_cont, i)
+        out.append(([torch.from_numpy(xcat), torch.from_numpy(xcont)], torch.from_numpy(y)))
+    return out
+
+
+def test_g16_rossmann_curve_oracle():
+    """The oracle (restated StructuredDataNet + restated Optimizer.step) against the REFERENCE's own 20-step fp32 curve at bs 1024 x 32
+    columns x fc [1000, 500, 1] (golden G16, oracle/gen_golden_curves.py): every step to 1e-5 — pins the oracle at full size."""
+    g = load_golden('g16_rossmann_curve')
+    assert [int(c) for c in g['cards']] == synth.ROSSMANN_CARDS
+    assert (np.abs(g['losses.f32'] - g['losses.f64']) / np.abs(g['losses.f64'])).max() < 3e-4
+    dims = [int(d) for d in g['emb_dims']]
+    net = RNets.StructuredDataNet('cont', list(zip(synth.ROSSMANN_CARDS, dims)), int(g['n_cont']), [1000, 500, 1], output_range=[5, 12])
+    synth.fill_module_(net, seed=int(g['init_seed']))
+    assert [n for n, _ in net.named_parameters()] == [str(s) for s in g['param_names']]
+    net.train()
+    params = [p for _, p in net.named_parameters()]
+    state = RM.OptimState(params)
+    lr, wd = [float(v) for v in g['lr']], float(g['wd'])
+    lrs = [lr[group_of(n)] for n, _ in net.named_parameters()]
+    losses = []
+    for (xcat, xcont), y in _g16_batches(g):
+        for p in params:
+            p.grad = None
+        loss = nn.MSELoss()(net(xcat, xcont), y)
+        loss.backward()
+        losses.append(loss.item())
+        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [wd] * len(params), 'adam')
+    rel = np.abs(np.array(losses) - g['losses.f32']) / np.abs(g['losses.f32'])
+    assert rel.max() < 1e-5, rel
+    abs_sums = np.array([p.double().abs().sum().item() for p in params])
+    assert_close(abs_sums, g['after.abs_sums.f32'], 1e-5, 1e-7, 'parameter |.|-sums after 20 steps')
+
+
+@pytest.mark.gpu
+def test_g16_rossmann_curve_hip_learner_every_step_within_1e3():
+    """The product Learner on the GPU (hipGraph replay on by default for this head) against the same reference curve: |hip - ref32| <=
+    1e-3 |ref32| on every one of the 20 steps, parameter |.|-sums afterwards within 3x the reference's fp32-vs-fp64 gap + 1e-3."""
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    g = load_golden('g16_rossmann_curve')
+    labels = [{i: i for i in range(c)} for c in synth.ROSSMANN_CARDS]
+    net = StructuredDataNet('cont', 32, int(g['n_cont']), labels, [1000, 500, 1], output_range=[5, 12])
+    assert [e.emb.weight.shape[1] for e in net.embeddings] == [int(d) for d in g['emb_dims']]
+    synth.fill_module_(net, seed=int(g['init_seed']))
+    assert [n for n, _ in net.named_parameters()] == [str(s) for s in g['param_names']]
+    batches = _g16_batches(g)
+
+    class D:
+        pass
+    d = D(); d.train_dl = d.val_dl = batches; d.bs = int(g['bs']); d.target_type = 'cont'
+    set_default_device(DEV)
+    Learner.verbose = False
+    learner = Learner('/tmp/nnl_test_g16', d, net, optimizer='Adam')
+    learner.init_optimizer(wd=float(g['wd']))
+    net.train()
+    lr = [float(v) for v in g['lr']]
+    losses = np.array([learner.train1minibatch([b[0][0].to(DEV), b[0][1].to(DEV)], b[1].to(DEV), lr) for b in batches])
+    rel = np.abs(losses - g['losses.f32']) / np.abs(g['losses.f32'])
+    print('rel |hip - ref32|', np.array2string(rel, precision=1))
+    assert (rel <= 1e-3).all(), 'step losses off the reference fp32 curve: worst %.2e at step %d' % (rel.max(), rel.argmax())
+    abs_sums = np.array([p.double().abs().sum().item() for _, p in net.named_parameters()])
+    a32, a64 = g['after.abs_sums.f32'], g['after.abs_sums.f64']
+    tol = 3 * np.abs(a32 - a64) + 1e-3 * np.abs(a64) + 1e-6
+    bad = np.nonzero(np.abs(abs_sums - a64) > tol)[0]
+    assert len(bad) == 0, [(str(g['param_names'][i]), abs_sums[i], a32[i], a64[i]) for i in bad[:5]]
+    net.eval()
+    with torch.no_grad():
+        pred = net(batches[0][0][0].to(DEV), batches[0][0][1].to(DEV))
+    assert_close(pred[:64], g['eval_pred0.f32'], 1e-3, 1e-3, 'eval-mode prediction after the 20 steps')

@@ -153,3 +153,39 @@ def test_g13b_oracle_first_steps_at_baseline_size():
         loss.backward()
         RM.optimizer_step(params, [p.grad for p in params], state, lrs, [float(g['wd'])] * len(params), 'sgd')
         assert abs(loss.item() - g['losses.f32'][i]) <= 2e-5 * abs(g['losses.f32'][i]), (i, loss.item(), g['losses.f32'][i])
+
+
+def test_g13c_oracle_first_steps_frozen_bn_at_baseline_size():
+    """the CPU oracle reproduces the first 3 steps of the REFERENCE's frozen-BatchNorm curve at BASELINE configs[1]'s size (G13c: ResNet-34,
+    224 x 224, bs 64, bn_freeze('all') + running statistics, SGD momentum, body lr large enough that the head-only curve leaves the full
+    one by >= 20 %) — BatchNorm parameters are out of the optimizer (Learner.py:248-264), the layers run on their running statistics."""
+    import torch.nn as nn
+    from oracle import reference_math as RM, reference_nets as RNets
+    g = load_golden('g13c_resnet34_frozen_bn_curve')
+    assert (np.abs(g['losses.f32.headonly'] - g['losses.f32']) / g['losses.f32']).max() >= 0.2
+    assert (np.abs(g['losses.f32'] - g['losses.f64']) / g['losses.f64']).max() < 3e-4
+    N, S = int(g['N']), int(g['S'])
+    onet = RNets.ImageClassificationNet(RNets.resnet34(), 2, 512, drops=(0., 0.), probe_sz=(S, S))
+    synth.fill_reference_init_(onet, seed=int(g['init_seed']))
+    synth.tame_residual_branches_(onet)
+    onet.train()
+    bn_params = set()
+    for m in onet.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            m.training = False
+            bn_params.update(id(p) for p in m.parameters())
+    names = [n for n, _ in onet.named_parameters()]
+    assert names == [str(s) for s in g['param_names']]
+    group = lambda n: 2 if n.startswith('head') else (0 if int(n.split('.')[1]) < 6 else 1)
+    train = [(n, p) for n, p in onet.named_parameters() if id(p) not in bn_params]
+    params = [p for _, p in train]
+    lrs = [float(g['lr'][group(n)]) for n, _ in train]
+    state = RM.OptimState(params)
+    for i in range(3):
+        x, y = synth.curve_batch_images(N, S, 1400 + i)
+        for p in onet.parameters():
+            p.grad = None
+        loss = nn.CrossEntropyLoss()(onet(x), y)
+        loss.backward()
+        RM.optimizer_step(params, [p.grad for p in params], state, lrs, [float(g['wd'])] * len(params), 'sgd')
+        assert abs(loss.item() - g['losses.f32'][i]) <= 2e-5 * abs(g['losses.f32'][i]), (i, loss.item(), g['losses.f32'][i])
