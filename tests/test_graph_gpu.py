@@ -177,9 +177,9 @@ def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
         os.environ.pop('NNL_DIST_REPLAY_OVERLAP', None)
         assert n1 == 0 and n2 == 1 and n3 == 1
         # round 4: the captured backward carries one signal kernel per bucket; every replay's collectives were enqueued behind wait kernels
-        # on the side stream (6 replays x all buckets), none timed out; with the overlap switched off they follow the whole replay
-        assert g2.overlap is not None and g2.overlap.signalled == len(g2.buckets) and g2.overlap_launches == 6 * len(g2.buckets)
-        assert int(g2.overlap.flags.min().item()) == g2.overlap.replays == 6 and int(g2.overlap.step.item()) == 6
+        # on the side stream (7 replays — the capture step's own and six more — x all buckets), none timed out; with the overlap switched off they follow the whole replay
+        assert g2.overlap is not None and g2.overlap.signalled == len(g2.buckets) and g2.overlap_launches == 7 * len(g2.buckets)
+        assert int(g2.overlap.flags.min().item()) == g2.overlap.replays == 7 and int(g2.overlap.step.item()) == 7
         assert g3.overlap is None and g3.overlap_launches == 0
         assert_close(l1, l0, 1e-5, 1e-6, 'eager DP vs eager')
         assert_close(l2, l1, 1e-5, 1e-6, 'graph DP (overlapped collectives) vs eager DP')
