@@ -6,6 +6,7 @@
 #include "igemm_taps.h"
 #include "wino.h"
 #include "igemm_wgrad.h"
+#include "igemm_wgrad2d.h"
 
 #ifdef NNL_TAPS_TIMING
 static void* g_wgrad_dbg = nullptr;
@@ -724,6 +725,133 @@ int launch_wgrad_wino(const float* dy, const float* x, float* slabs, const nnl_c
   return NNL_OK;
 }
 
+// ---- the weight gradient in the 2-D Winograd F(2x2, 3x3) domain (igemm_wgrad2d.h, round 4) ----
+// dW [K][3][3][C] from the slabs dU [splits][K][16][C]: 256 threads = 16 (k, c4) items x 16 positions; thread (item, position) sums its
+// position over the slabs in index order (bitwise reproducible), the sixteen sums of an item meet in LDS, and nine of its threads
+// apply dW = G^T dU G, G = (1,0,0 / .5,.5,.5 / .5,-.5,.5 / 0,0,1).
+__global__ __launch_bounds__(256) void wino2d_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, long n_items, int C4,
+                                                                   int splits, long slab4) {
+  __shared__ f32x4 du[16][16];
+  const int it = threadIdx.x >> 4, pos = threadIdx.x & 15;
+  const long i = (long)blockIdx.x * 16 + it;                           // over (k, c4)
+  const long c4 = i % C4, k = i / C4;
+  f32x4 u = {0.f, 0.f, 0.f, 0.f};
+  if (i < n_items) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(part) + (k * 16 + pos) * C4 + c4;
+    for (int s0 = 0; s0 < splits; s0 += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (s0 + e < splits) v[e] = src[(long)(s0 + e) * slab4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (s0 + e < splits) u += v[e];
+    }
+  }
+  du[it][pos] = u;
+  __syncthreads();
+  if (pos < 9 && i < n_items) {
+    const int r = pos / 3, sx = pos - r * 3;
+    // G^T column weights of filter tap t over positions 0..3: t = 0: (1, .5, .5, 0), t = 1: (0, .5, -.5, 0), t = 2: (0, .5, .5, 1)
+    const float gr[4] = {r == 0 ? 1.f : 0.f, 0.5f, r == 1 ? -0.5f : 0.5f, r == 2 ? 1.f : 0.f};
+    const float gs[4] = {sx == 0 ? 1.f : 0.f, 0.5f, sx == 1 ? -0.5f : 0.5f, sx == 2 ? 1.f : 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      f32x4 row = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row += gs[b] * du[it][a * 4 + b];
+      acc += gr[a] * row;
+    }
+    reinterpret_cast<f32x4*>(dw)[(k * 9 + pos) * C4 + c4] = acc;
+  }
+}
+
+// NNL_WGRAD_WINO2D: 0 never, 2 wherever it is legal, 1 (default) where it measured faster than the 1-D domain / the direct kernel
+// (tools/bench_conv.py --ab NNL_WGRAD_WINO2D=0,2; profiles/r4_wgrad2d_*.log)
+bool wgrad_wino2d_ok(const nnl_conv_geom_t* g) {
+  const int mode = NNL_ENV_INT("NNL_WGRAD_WINO2D", 1);
+  if (mode == 0 || NNL_ENV_INT("NNL_WGRAD_WINO", 1) == 0) return false;
+  if (g->R != 3 || g->S != 3 || g->stride != 1 || g->pad != 1 || g->C % 64 != 0 || g->K % 4 != 0 || g->H < 2 || g->W < 2) return false;
+  const long quads = (long)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2);
+  if (quads < 512 || !wgrad_v2_ok((long)g->N * g->H * g->W * g->K, (long)g->N * g->H * g->W * g->C, quads)) return false;
+  if (mode == 2) return true;
+  return quads >= NNL_ENV_INT("NNL_WGRAD_WINO2D_MIN_QUADS", 1024);
+}
+
+// Tile / wave-group choice of the 2-D domain, measured (tools/bench_conv.py --ab NNL_WGRAD_WINO_TILE / NNL_WGRAD_KG under NNL_WGRAD_WINO2D=2,
+// profiles/r4_wgrad2d_*.log): the 64x64 tile with FOUR wave groups per workgroup (four neighbouring splits meet in LDS: a quarter of the
+// slabs) wherever the plan has at least four splits (56^2 / 28^2 / 14^2 stages at 64 images: 0.105 / 0.101 / 0.100 -> 0.094 / 0.093 /
+// 0.092 ms); the 128x128 tile where the 64x64 plan has fewer (7^2 stage: 0.127 -> 0.114 ms).  NNL_WGRAD_WINO2D_RULE=0: the generic planner.
+WgradPlan plan_wgrad_wino2d(const nnl_conv_geom_t* g) {
+  const long quads = (long)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2);
+  WgradPlan pl = plan_wgrad(g->K, 16 * g->C, quads, g->C);
+  if (NNL_ENV_INT("NNL_WGRAD_WINO2D_RULE", 1) == 0 || NNL_ENV_INT("NNL_WGRAD_WINO_TILE", -1) >= 0 || NNL_ENV_INT("NNL_WGRAD_KG", -1) >= 0) return pl;
+  auto with_tile = [&](int bt, int splits_target) {
+    WgradPlan q{};
+    q.bm = q.bn = bt; q.grid_m = (int)nnl_cdiv(g->K, bt); q.grid_n = (int)nnl_cdiv(16L * g->C, bt); q.kg = 1;
+    const long tiles = (long)q.grid_m * q.grid_n;
+    long sp = splits_target > 0 ? splits_target : (256L * 4 + tiles - 1) / tiles;            // ~4 workgroups per CU
+    const long max_sp = quads / 256 > 0 ? quads / 256 : 1;
+    if (sp > max_sp) sp = max_sp;
+    if (sp < 1) sp = 1;
+    const long k1 = nnl_cdiv(nnl_cdiv(quads, sp), 32) * 32;
+    q.k_per_split = (int)k1; q.splits = (int)nnl_cdiv(quads, k1);
+    return q;
+  };
+  const bool big = g->K >= 128 && g->C % 128 == 0;
+  // big problems on wide layers (RetinaNet heads / FPN on P3: 16384 quads x 256 x 256): the 128x128 tile's operand reuse wins (0.430 -> 0.374 ms)
+  if (big && (double)quads * g->K * g->C >= NNL_ENV_INT("NNL_WGRAD_WINO2D_BIG_E6", 500) * 1e6) return pl.bm == 128 ? pl : with_tile(128, 0);
+  WgradPlan p64 = pl.bm == 64 ? pl : with_tile(64, 0);
+  if (p64.splits >= 4) {                                                // four neighbouring splits -> one workgroup of four wave groups
+    const long sp = nnl_cdiv(p64.splits, 4);
+    const long k1 = nnl_cdiv(nnl_cdiv(quads, sp), 128L) * 128L;          // each group's share stays a multiple of 32 quads
+    if (k1 / 4 >= NNL_ENV_INT("NNL_WGRAD_WINO2D_MIN_GROUP", 700)) {      // (shorter shares: prologue / group reduction dominate — 28^2 at 32 images: -23 %)
+      p64.kg = 4; p64.k_per_split = (int)k1; p64.splits = (int)nnl_cdiv(quads, k1);
+      return p64;
+    }
+    return pl;
+  }
+  if (big) return pl.bm == 128 ? pl : with_tile(128, 0);
+  return p64;
+}
+
+int launch_wgrad_wino2d(const float* dy, const float* x, float* slabs, const nnl_conv_geom_t* g, const WgradPlan& pl, hipStream_t s) {
+  IgemmWgrad2dParams q{};
+  q.a = dy; q.b = x; q.y = slabs;
+  q.a_bytes = (unsigned)((long)g->N * g->H * g->W * g->K * 4); q.b_bytes = (unsigned)((long)g->N * g->H * g->W * g->C * 4);
+  q.H = g->H; q.W = g->W; q.C = g->C; q.H2 = (g->H + 1) / 2; q.W2 = (g->W + 1) / 2;
+  q.Mc = g->K; q.Nc = 16 * g->C; q.Kp = (int)((long)g->N * q.H2 * q.W2);
+  q.splits = pl.splits; q.k_per_split = pl.k_per_split; q.grid_m = pl.grid_m; q.grid_n = pl.grid_n;
+  q.n_fast = 1;
+  const dim3 grid(pl.grid_m * pl.grid_n * pl.splits);
+  auto lds_bytes = [](int bt, int bk, int kg) { return (size_t)kg * 2 * bk * 2 * bt * sizeof(float); };
+#define NNL_WGRAD2D_LAUNCH(BT_, BK_, KG_)                                                                                        \
+  do {                                                                                                                           \
+    const size_t lb = lds_bytes(BT_, BK_, KG_);                                                                                  \
+    if (lb > 64 * 1024) {                                                                                                        \
+      static bool attr_set = false;                                                                                              \
+      if (!attr_set) {                                                                                                           \
+        NNL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad2d_kernel<BT_, BK_, true, KG_>),             \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));                                 \
+        attr_set = true;                                                                                                         \
+      }                                                                                                                          \
+    }                                                                                                                            \
+    hipLaunchKernelGGL((igemm_wgrad2d_kernel<BT_, BK_, true, KG_>), grid, dim3(256 * KG_), lb, s, q);                            \
+  } while (0)
+  if (pl.bm == 128) {
+    if (pl.kg == 2) NNL_WGRAD2D_LAUNCH(128, 16, 2);
+    else NNL_WGRAD2D_LAUNCH(128, 16, 1);
+  } else if (pl.k_per_split % 32 == 0) {
+    if (pl.kg == 4) NNL_WGRAD2D_LAUNCH(64, 32, 4);
+    else if (pl.kg == 2) NNL_WGRAD2D_LAUNCH(64, 32, 2);
+    else NNL_WGRAD2D_LAUNCH(64, 32, 1);
+  } else {
+    NNL_WGRAD2D_LAUNCH(64, 16, 1);
+  }
+#undef NNL_WGRAD2D_LAUNCH
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
 }  // namespace
 
 int nnl_internal_gemm_nt(const float* a, const float* b, float* y, const float* bias, const float* add, int M, int N,
@@ -1133,6 +1261,8 @@ extern "C" int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx,
 
 extern "C" size_t nnl_conv2d_wgrad_workspace_bytes(const nnl_conv_geom_t* g) {
   if (!g || g->K <= 0 || g->C <= 0) return 0;
+  if (wgrad_wino2d_ok(g))                                   // the 2-D Winograd-domain slabs [splits][K][16*C] (always: dU is folded to dW from them)
+    return (size_t)plan_wgrad_wino2d(g).splits * g->K * 16 * g->C * sizeof(float);
   if (wgrad_wino_ok(g))                                     // the Winograd-domain slabs [splits][K][12*C] (always: dU is folded to dW from them)
     return (size_t)plan_wgrad_wino(g).splits * g->K * 12 * g->C * sizeof(float);
   const WgradPlan pl = plan_wgrad(g->K, g->R * g->S * g->C, (long)g->N * g->P * g->Q);
@@ -1158,6 +1288,17 @@ extern "C" int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, cons
     return nnl_set_error(NNL_ERR_WORKSPACE, "conv2d_wgrad: workspace %zu B < required %zu B", workspace_bytes, need);
   p.y = pl.splits > 1 ? (float*)workspace : dw;
   NnlProfScope prof(NNL_PROF_CONV_WGRAD, s, 2.0 * p.Kp * (double)p.Mc * p.Nc);
+  if (wgrad_wino2d_ok(g)) {                                 // 2-D Winograd-domain weight gradient (igemm_wgrad2d.h) + the fold-back reduce
+    const WgradPlan wp = plan_wgrad_wino2d(g);
+    nnl_prof_exec_frac(1.0 / 2.25);
+    int st2 = launch_wgrad_wino2d(dy, x, (float*)workspace, g, wp, s);
+    if (st2) return st2;
+    const long n_items = (long)g->K * (g->C / 4);
+    hipLaunchKernelGGL(wino2d_wgrad_finish_kernel, dim3((unsigned)nnl_cdiv(n_items, 16L)), dim3(256), 0, s, (const float*)workspace, dw, n_items,
+                       g->C / 4, wp.splits, (long)g->K * 16 * (g->C / 4));
+    NNL_CHECK_LAUNCH();
+    return NNL_OK;
+  }
   if (wgrad_wino_ok(g)) {                                   // Winograd-domain weight gradient (igemm_wgrad.h, WINO) + the fold-back reduce
     const WgradPlan wp = plan_wgrad_wino(g);
     nnl_prof_exec_frac(1.0 / 1.5);

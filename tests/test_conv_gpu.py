@@ -268,30 +268,38 @@ def test_shared_conv_weight_under_gradsync_is_not_aliased():
     assert sync.direct_writes >= 2, 'the single-use convolution should still write its gradient in place'
 
 
-@pytest.mark.parametrize('case', [(16, 64, 16, 16, 64), (2, 128, 32, 32, 128), (12, 256, 14, 14, 256), (2, 64, 64, 64, 36), (48, 128, 8, 6, 320)],   # >= 1024 output pairs each
-                         ids=str)
-def test_wgrad_winograd_domain(case, monkeypatch):
-    """The weight gradient of a 3x3 / stride 1 / pad 1 convolution computed in the Winograd F(2,3) domain (igemm_wgrad_kernel WINO +
-    wino_wgrad_finish_kernel, forced with NNL_WGRAD_WINO=2) against the direct wgrad kernel (=0) and torch CPU fp32; both bitwise
-    reproducible run to run."""
+@pytest.mark.parametrize('case', [(16, 64, 16, 16, 64), (2, 128, 32, 32, 128), (12, 256, 14, 14, 256), (2, 64, 64, 64, 36), (48, 128, 8, 6, 320),   # >= 1024 output pairs each
+                                  (64, 128, 7, 7, 64), (12, 64, 15, 13, 128)], ids=str)                                                      # odd sizes (2-D domain only)
+@pytest.mark.parametrize('domain', ['1d', '2d'])
+def test_wgrad_winograd_domain(case, domain, monkeypatch):
+    """The weight gradient of a 3x3 / stride 1 / pad 1 convolution computed in a Winograd domain — F(2,3) along the width (igemm_wgrad_kernel
+    WINO + wino_wgrad_finish_kernel, forced with NNL_WGRAD_WINO=2, NNL_WGRAD_WINO2D=0) or F(2x2,3x3) over output quads (round 4:
+    igemm_wgrad2d_kernel + wino2d_wgrad_finish_kernel, NNL_WGRAD_WINO2D=2; odd heights / widths included) — against the direct wgrad kernel
+    (NNL_WGRAD_WINO=0) and torch CPU fp32; every path bitwise reproducible run to run."""
     from neuralnetworklibrary_amd import ops
     from neuralnetworklibrary_amd._lib import lib
     N, C, H, W, K = case
+    if domain == '1d' and W % 2:
+        pytest.skip('the 1-D domain needs an even width')
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
     dy = torch.randn(N, K, H, W, generator=g)
 
-    def run(mode):
-        monkeypatch.setenv('NNL_WGRAD_WINO', mode); lib.nnl_reload_env()
+    def run(wino, wino2d):
+        monkeypatch.setenv('NNL_WGRAD_WINO', wino); monkeypatch.setenv('NNL_WGRAD_WINO2D', wino2d); lib.nnl_reload_env()
         xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
         ops.conv2d(xg, wg, None, 1, 1, False).backward(dy.to(DEV))
         return wg.grad.detach().clone()
 
-    dw_w, dw_w2, dw_d = run('2'), run('2'), run('0')
-    monkeypatch.delenv('NNL_WGRAD_WINO'); lib.nnl_reload_env()
+    forced = ('2', '0') if domain == '1d' else ('1', '2')
+    dw_w, dw_w2, dw_d = run(*forced), run(*forced), run('0', '0')
+    dw_other = run('2', '0') if domain == '2d' and W % 2 == 0 else None
+    monkeypatch.delenv('NNL_WGRAD_WINO'); monkeypatch.delenv('NNL_WGRAD_WINO2D'); lib.nnl_reload_env()
     assert torch.equal(dw_w, dw_w2), 'Winograd-domain wgrad must be bitwise reproducible'
     assert not torch.equal(dw_w, dw_d), 'the forced path did not run (same bits as the direct kernel)'
+    if dw_other is not None:
+        assert not torch.equal(dw_w, dw_other), 'the 2-D path did not run (same bits as the 1-D domain)'
     ref = torch.nn.grad.conv2d_weight(x, (K, C, 3, 3), dy, padding=1)
     sc = ref.abs().max().item()
     assert_close(dw_w, dw_d, rtol=1e-5, atol=2e-6 * sc, msg='dw Winograd vs direct')
