@@ -15,6 +15,7 @@
 #include "wino.h"
 #include "wino_filter.h"
 #include "igemm_taps.h"
+#include <algorithm>
 
 namespace {
 
@@ -32,6 +33,8 @@ struct Wino2Params {
   int prio;            // 1: raise the wave priority around the MFMA block (NNL_WINO2_PRIO)
   int fold_skip;       // 1 (default): a position is folded only into the output tiles it feeds (NNL_WINO2_FOLD_SKIP=0: all four, A/B)
   int M4;              // N * H2 * W2 rows
+  unsigned mg_W2, mg_H2;   // ceil(2^32 / d) (0: d = 1): quad row -> (n, i, j) by multiply-high instead of division (the epilogue did 32 runtime
+                       // divisions per thread and tile: most of the 12 us fixed cost per workgroup generation the planner had fitted)
   int Nc;
   int relu;
   int grid_m, grid_n;
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
   const int tile_m = logical / p.grid_n, tile_n = logical - tile_m * p.grid_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kc = tid % KC, lrow = tid / KC;
+  auto qdiv = [](int n, unsigned mg) { return mg ? (int)__umulhi((unsigned)n, mg) : n; };          // n / d, mg = ceil(2^32 / d); 0: d = 1
   const __amdgpu_buffer_rsrc_t ra_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.a), 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rb_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b), 0, (int)p.b_bytes, 0x00020000);
 
@@ -90,8 +94,8 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     const int m = m0 + lrow + i * RPP;
     const bool valid = m < p.M4;
     const int mm = valid ? m : 0;
-    const int l2 = mm / p.W2, j = mm - l2 * p.W2;              // l2 = n * H2 + i
-    const int n = l2 / p.H2, ii = l2 - n * p.H2;
+    const int l2 = qdiv(mm, p.mg_W2), j = mm - l2 * p.W2;      // l2 = n * H2 + i
+    const int n = qdiv(l2, p.mg_H2), ii = l2 - n * p.H2;
     a_off[i] = (((n * p.H + 2 * ii - 1) * p.W + 2 * j - 1) * p.C + kc * 4) * 4;
     unsigned rm = 0, cm = 0;
     if (valid) {
@@ -272,12 +276,13 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     if (ticket != nslices - 1) return;
     if (tid == 0) __hip_atomic_store(&p.tile_counters[logical], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
     float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k16 = 0; k16 < 16; ++k16) {             // 256 slab rows x 16 float4 columns = 16 float4 per thread
-      const int idx4 = tid + k16 * 256, srow = idx4 >> 4, c4 = n0 + (idx4 & 15) * 4;
-      const int row = m0 + (srow >> 2), h = srow & 3;
+    // 256 slab rows (quad row, sub-pixel) x 16 float4 columns: thread -> sub-pixel h = (tid >> 4) & 3, quad rows (tid >> 6) + 4 k
+    const int h = (tid >> 4) & 3, c4 = n0 + (tid & 15) * 4;
+    for (int k16 = 0; k16 < 16; ++k16) {
+      const int row = m0 + (tid >> 6) + 4 * k16;
       if (row >= p.M4 || c4 >= p.Nc) continue;
-      const int l2 = row / p.W2, j = row - l2 * p.W2;
-      const int n = l2 / p.H2, ii = l2 - n * p.H2;
+      const int l2 = qdiv(row, p.mg_W2), j = row - l2 * p.W2;
+      const int n = qdiv(l2, p.mg_H2), ii = l2 - n * p.H2;
       const int oh = 2 * ii + (h >> 1), ow = 2 * j + (h & 1);
       if (oh >= p.H || ow >= p.W) continue;          // the missing outputs of an odd height / width
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -324,6 +329,21 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
   constexpr int LDT = 68;
   float* tl = &lds[0][0];                                  // 64 x 68 floats (BK 16: 5120 available)
   float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
+  // this thread's four quad rows (tid >> 4) + 16 k, columns c4: output pixel base and which of the four sub-pixels exist — computed
+  // ONCE (round 4: it was recomputed, with two runtime divisions, for every sub-pixel pass)
+  const int c4 = n0 + (tid & 15) * 4;
+  int pb[4];
+  unsigned okm[4];
+#pragma unroll
+  for (int k4 = 0; k4 < 4; ++k4) {
+    const int row = m0 + (tid >> 4) + 16 * k4;
+    const int l2 = qdiv(row, p.mg_W2), j = row - l2 * p.W2;
+    const int n = qdiv(l2, p.mg_H2), ii = l2 - n * p.H2;
+    pb[k4] = ((n * p.H + 2 * ii) * p.W + 2 * j) * p.Nc + c4;
+    const bool ok = row < p.M4 && c4 < p.Nc, h1 = 2 * ii + 1 < p.H, w1 = 2 * j + 1 < p.W;
+    okm[k4] = ok ? (1u | (w1 ? 2u : 0u) | (h1 ? 4u : 0u) | ((h1 && w1) ? 8u : 0u)) : 0u;
+  }
+  const int wrow = p.W * p.Nc;
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
     if (h) __syncthreads();
@@ -333,15 +353,9 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     __syncthreads();
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) {
-      const int idx4 = tid + k4 * 256, rl = idx4 >> 4, c4 = n0 + (idx4 & 15) * 4;
-      const int row = m0 + rl;
-      if (row >= p.M4 || c4 >= p.Nc) continue;
-      const int l2 = row / p.W2, j = row - l2 * p.W2;
-      const int n = l2 / p.H2, ii = l2 - n * p.H2;
-      const int oh = 2 * ii + (h >> 1), ow = 2 * j + (h & 1);
-      if (oh >= p.H || ow >= p.W) continue;
-      f32x4 v = *reinterpret_cast<const f32x4*>(tl + rl * LDT + (idx4 & 15) * 4);
-      const long o = (((long)n * p.H + oh) * p.W + ow) * p.Nc + c4;
+      if (!((okm[k4] >> h) & 1u)) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(tl + ((tid >> 4) + 16 * k4) * LDT + (tid & 15) * 4);
+      const int o = pb[k4] + (h >> 1) * wrow + (h & 1) * p.Nc;
       if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
       if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
       if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
@@ -446,6 +460,7 @@ long quads(int N, int H, int W) { return (long)N * ((H + 1) / 2) * ((W + 1) / 2)
 bool nnl_wino2_ok(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
   if (R != 3 || S != 3 || stride != 1 || pad != 1 || W < 2 || H < 2 || Cin % 16 != 0 || Nc % 4 != 0) return false;
   const long a_b = (long)N * H * W * Cin * 4, b_b = (long)Nc * 16 * Cin * 4, y_b = (long)N * H * W * Nc * 4;
+  if ((quads(N, H, W) + 128) * (long)std::max((W + 1) / 2, (H + 1) / 2) >= (1L << 32)) return false;        // the kernel's multiply-high divisions
   return a_b < (1L << 31) && b_b < (1L << 31) && y_b < (1L << 31);
 }
 
@@ -478,6 +493,10 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
     p.fold_skip = NNL_ENV_INT("NNL_WINO2_FOLD_SKIP", 1);
   }
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.H2 = (q.H + 1) / 2; p.W2 = (q.W + 1) / 2; p.M4 = (int)M4; p.Nc = q.Nc; p.relu = q.relu;
+  {
+    auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ULL << 32) + d - 1) / (unsigned)d); };
+    p.mg_W2 = magic(p.W2); p.mg_H2 = magic(p.H2);
+  }
   p.grid_m = (int)nnl_cdiv(M4, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
   p.bn_part = q.bn_part; p.bn_pivot = q.bn_pivot;
   const long T = (long)p.grid_m * p.grid_n;
