@@ -236,7 +236,7 @@ class LanguageModelDecoder(nn.Module):
         self.fixed_mask = None
 
     def forward(self, enc_out):
-        pred = ops.linear(self.drop(enc_out, self.fixed_mask), self.lin.weight, None)      # [seq, bs, V]
+        pred = ops.linear(self.drop(enc_out, self.fixed_mask), self.lin.weight, None, wgrad_side=True)      # [seq, bs, V]; its 170-GFLOP dW runs beside the BPTT
         return pred.permute(1, 2, 0), enc_out
 
 

@@ -99,6 +99,9 @@ class Optimizer(object):
         self._fused.replay_update(capture, lrs, decays, self.clip)
 
     def step(self):
+        if torch.cuda.is_available():
+            from .. import ops
+            ops.side_join()                                 # (weight gradients on the side stream: a no-op unless a backward used it)
         if self.grad_sync is not None:
             self.grad_sync.finish()
         fused = self._fused_stepper()

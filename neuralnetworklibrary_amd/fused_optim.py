@@ -114,6 +114,8 @@ class FusedStep:
 
     def step(self, lrs, decays, clip):
         """lrs / decays: one value per torch param group (decay = 1 - wd*lr or 1.0)."""
+        from . import ops
+        ops.side_join()                                     # weight gradients computed on the side stream (ops._Side) must have landed
         self._init_state()                                  # state may have been replaced by opt.load_state_dict
         desc = np.zeros(len(self.params), dtype=_DESC)
         keep = []

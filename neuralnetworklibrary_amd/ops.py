@@ -339,6 +339,11 @@ def prepare_backward(model):
 
 
 def finish_backward():
+    side_join()
+    _finish_backward_impl()
+
+
+def _finish_backward_impl():
     "closes the window of everything prepare_forward / prepare_backward exposed (the optimizer is about to change the weights)"
     _WT_ACTIVE.clear()
     _WINO_U_FWD.clear()
@@ -421,6 +426,66 @@ class GradSlot:
         self.closed = False
 
 
+
+# ---- weight gradients on a SIDE STREAM (round 4) ---------------------------------------------------------------------------------
+# The language model's backward is a chain of latency-bound launches (210 BPTT timesteps x 2 kernels: <= 256 small workgroups and ~6 us
+# of dependent-launch gap each) with five big weight-gradient GEMMs hanging off it (decoder 170 GFLOP, dW_ih / dW_hh 47 GFLOP each)
+# that nothing downstream in backward depends on.  Call sites that opt in (`linear(..., wgrad_side=True)`, ops_text._LSTMRecurrence)
+# launch those GEMMs on a second HIP stream, where they fill the CUs the recurrence leaves idle; the main stream joins it in
+# finish_backward() / before the fused optimizer step (side_join).  Safety: only when the parameter has no gradient yet (autograd then
+# takes the produced tensor as `.grad` without touching its data — an accumulation kernel on the main stream would race), not under
+# data parallelism (the bucket hooks copy on the main stream), not while a hipGraph is being captured; every tensor the side launches
+# touch is recorded on that stream for the caching allocator; a gradient that needs un-padding is made dense ON the side stream (a strided view would be cloned by autograd
+# on the main stream: a race — found by tests/test_text.py).  Measured: the GEMMs do run beside the recurrence, but they take its CUs: kernel times
+# LSTM 7.08 -> 9.07 ms, wgrad 3.73 -> 4.39 ms, wall 17.33 -> 17.21 ms — hence opt-in (NNL_WGRAD_SIDE_STREAM=1), kept for the record.
+class _Side:
+    stream = None
+    used = False
+    enabled = os.environ.get('NNL_WGRAD_SIDE_STREAM', '0') == '1'      # OPT-IN: measured +0.7 % on the LM step (profiles/r4_lm_side_stream_ab.log)
+    pending_param = None          # set by linear(..., wgrad_side=True) for the _Conv2d.forward that follows
+
+
+def side_ok(param):
+    return (_Side.enabled and param is not None and param.is_cuda and param.grad is None and getattr(param, '_nnl_grad_dst', None) is None
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def side_run(fn, tensors):
+    "fn() launches its kernels on the current stream: run it with the side stream current, after everything queued on the main stream so far"
+    main = torch.cuda.current_stream()
+    if _Side.stream is None:
+        _Side.stream = torch.cuda.Stream()
+    s = _Side.stream
+    s.wait_stream(main)
+    with torch.cuda.stream(s):
+        fn()
+    for t in tensors:
+        if t is not None:
+            t.record_stream(s)
+    _Side.used = True
+
+
+def _side_wgrad(run_w, tensors, dwn, K, c_in):
+    "a linear layer's weight gradient on the side stream; returns a DENSE [K, c_in, 1, 1] tensor (un-padded there, not by autograd on the main stream)"
+    if K == dwn.shape[0] and c_in == dwn.shape[3]:
+        side_run(run_w, tensors)
+        return from_nhwc(dwn)
+    dense = torch.empty((K, c_in, 1, 1), dtype=torch.float32, device=dwn.device)
+
+    def run():
+        run_w()
+        dense.view(K, c_in).copy_(dwn.view(dwn.shape[0], dwn.shape[3])[:K, :c_in])
+    side_run(run, tuple(tensors) + (dense,))
+    return dense
+
+
+def side_join():
+    "the main stream waits for the side-stream weight gradients (before anything reads them: optimizer, accumulation into a tied weight)"
+    if _Side.used:
+        torch.cuda.current_stream().wait_stream(_Side.stream)
+        _Side.used = False
+
+
 class _Conv2d(torch.autograd.Function):
     """nn.Conv2d forward/backward (reference Applications/VisionModels/retinanet.py:26-28,66-71,106-124,169-185,
     241-257,304,345) on the fp32-MFMA implicit-GEMM kernels; optional fused bias + ReLU epilogue."""
@@ -430,6 +495,7 @@ class _Conv2d(torch.autograd.Function):
         require_cuda(x, weight, bias)
         ctx.slot = slot
         ctx.give_slot = give_slot
+        ctx.side_param, _Side.pending_param = _Side.pending_param, None      # linear(..., wgrad_side=True): the parameter whose gradient may go to the side stream
         ctx.grad_dst = getattr(weight, '_nnl_grad_dst', None)     # data parallel: the flat all-reduce bucket (dist.GradSync)
         ctx.uses = getattr(weight, '_nnl_uses', None)             # forward uses of this weight in the current step
         if ctx.uses is not None:
@@ -547,8 +613,12 @@ class _Conv2d(torch.autograd.Function):
                 dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
             ws_bytes = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
             ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dyn.device)
-            check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
-            dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
+            run_w = lambda: check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
+            if side_ok(getattr(ctx, 'side_param', None)) and dst is None and g.R == 1 and g.S == 1:
+                dw = _side_wgrad(run_w, (xn, dyn, dwn, ws), dwn, K, ctx.c_in)
+            else:
+                run_w()
+                dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
         if db_gated is not None:
             db = db_gated
         elif ctx.has_bias and ctx.needs_input_grad[2]:
@@ -576,8 +646,12 @@ def _conv2d_backward_padded(ctx, dyn, wn, xn, g, K):
         dwn = torch.empty((g.K, g.R, g.S, g.C), dtype=torch.float32, device=dyn.device)
         ws_bytes = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
         ws = torch.empty(max(ws_bytes // 4, 1), dtype=torch.float32, device=dyn.device)
-        check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
-        dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
+        run_w = lambda: check(lib.nnl_conv2d_wgrad(ptr(xn), ptr(dyn), ptr(dwn), g, ptr(ws), ws_bytes, stream()))
+        if side_ok(getattr(ctx, 'side_param', None)) and g.R == 1 and g.S == 1:
+            dw = _side_wgrad(run_w, (xn, dyn, dwn, ws), dwn, K, ctx.c_in)
+        else:
+            run_w()
+            dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
     if ctx.has_bias and ctx.needs_input_grad[2]:
         db_full = torch.empty(g.K, dtype=torch.float32, device=dyn.device)
         cb = int(lib.nnl_colsum_workspace_bytes(g.N * g.P * g.Q, g.K))
@@ -673,12 +747,13 @@ def conv2d_with_bn_stats(x, weight, bias, stride, pad, bn_pivot, grad_slot=None,
     return _Conv2d.apply(x, weight, bias, int(stride), int(pad), False, grad_slot, bn_pivot, give_slot)
 
 
-def linear(x, weight, bias=None, relu=False):
+def linear(x, weight, bias=None, relu=False, wgrad_side=False):
     """y = x @ weight.T + bias [+ ReLU] (nn.Linear; reference General/Layers.py:39,146; Text.py:572) on the same
     fp32-MFMA implicit-GEMM kernels: a Linear is the 1x1 convolution of a 1x1 'image' per sample.  Leading dims of x
-    are flattened into rows."""
+    are flattened into rows.  wgrad_side: the weight gradient may be computed on the side stream (see _Side above)."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
+    _Side.pending_param = weight if (wgrad_side and weight.requires_grad) else None
     y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, int(relu), None, None)[0]
     return y.reshape(*lead, weight.shape[0])
 

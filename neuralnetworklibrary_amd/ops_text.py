@@ -48,6 +48,7 @@ class _LSTMRecurrence(torch.autograd.Function):
         check(lib.nnl_lstm_fwd(ptr(gx), ptr(w_pad), ptr(h0), ptr(c0), ptr(y), ptr(cy), ptr(gates), T, B, H, ptr(ws), wsb,
                                ptr(lstm_timeout_flag(dev)), stream()))
         ctx.save_for_backward(w_hh, h0, c0, y, cy, gates, wm)
+        ctx.side_param = w_raw if w_raw.requires_grad else None      # dW_hh may be computed on the side stream (ops._Side)
         return y, y[-1].clone(), cy[-1].clone()
 
     @staticmethod
@@ -84,13 +85,23 @@ class _LSTMRecurrence(torch.autograd.Function):
             dwp = torch.empty(Gp, Hp, dtype=torch.float32, device=dev)
             wb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))
             wws = torch.empty(max(wb // 4, 1), dtype=torch.float32, device=dev)
-            check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, Gp)), ptr(dwp), g, ptr(wws), wb, stream()))
             use, p, seed = ctx.drop
-            if use:                                          # dW_raw = dW * m, un-padded in the same pass
-                dw = torch.empty(G, H, dtype=torch.float32, device=dev)
-                check(lib.nnl_weight_drop(ptr(dwp), Hp, ptr(wm), ptr(dw), H, G, H, seed, p, stream()))
+            from . import ops as _ops
+            side = _ops.side_ok(getattr(ctx, 'side_param', None))
+            dense = use or (side and (Gp != G or Hp != H))   # (side stream: the un-padding copy happens THERE, not in autograd on the main stream)
+            dw = torch.empty(G, H, dtype=torch.float32, device=dev) if dense else dwp[:G, :H]
+
+            def run_w():
+                check(lib.nnl_conv2d_wgrad(ptr(hprev), ptr(dgates.view(T * B, Gp)), ptr(dwp), g, ptr(wws), wb, stream()))
+                if use:                                      # dW_raw = dW * m, un-padded in the same pass
+                    check(lib.nnl_weight_drop(ptr(dwp), Hp, ptr(wm), ptr(dw), H, G, H, seed, p, stream()))
+                elif dense:
+                    dw.copy_(dwp[:G, :H])
+            if side:
+                # the 47-GFLOP GEMM runs beside the latency-bound BPTT of the layer below (which needs only dgates, returned now)
+                _ops.side_run(run_w, (hprev, dgates, dwp, wws, dw, wm))
             else:
-                dw = dwp[:G, :H]
+                run_w()
         if Gp != G:
             from .ops import register_padded_grad
             register_padded_grad(dgates, Gp)                 # rows already padded with zeros: the input GEMM's backward uses them as is
@@ -105,7 +116,7 @@ def lstm_layer(x, h0, c0, w_ih, w_hh, b_ih, b_hh, weight_mask=None, weight_p=0.0
     from . import ops
     T, B, _ = x.shape
     H = w_hh.shape[1]
-    gx = ops.linear(x.reshape(T * B, -1), w_ih, b_ih + b_hh).view(T, B, 4 * H)
+    gx = ops.linear(x.reshape(T * B, -1), w_ih, b_ih + b_hh, wgrad_side=True).view(T, B, 4 * H)
     seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (weight_mask is None and weight_p > 0) else 0
     y, hT, cT = _LSTMRecurrence.apply(gx, w_hh, h0.reshape(B, H), c0.reshape(B, H), weight_mask, float(weight_p), seed)
     return y, (hT.view(1, B, H), cT.view(1, B, H))
@@ -131,6 +142,8 @@ class _EmbeddingRowMask(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        from . import ops as _ops
+        _ops.side_join()          # the tied decoder weight's gradient (side stream) is about to be accumulated into by autograd
         xi, rm = ctx.saved_tensors
         V, D, pad = ctx.meta
         dout = _f32c(dout)
