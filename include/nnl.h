@@ -395,6 +395,9 @@ int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float* h0, const 
 int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy,
                  const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, int64_t T, int64_t B,
                  int64_t H, void* workspace, size_t workspace_bytes, int32_t* err_flag, void* stream);
+/* The partition (KG x NG workgroups, k-slice Ks, column slice Ns, NT column tiles -> out5) the 2-D persistent BPTT kernel
+ * (csrc/lstm_bptt2.hip) would use for this shape; returns 0 when the shape does not fit it.  Host-only. */
+int nnl_debug_lstm_bptt2_plan(int64_t B, int64_t H, int32_t* out5);
 
 /* nn.MSELoss(reduction='mean') — `loss_func_dict['cont']` (General/Learner.py:20), the loss of the collaborative-filtering and
  * structured-data heads: *loss = mean((pred - target)^2) over n fp32 elements (one launch up to 65 536 samples, fixed-order sum);

@@ -28,6 +28,13 @@ hipError_t nnl_lstm_persist_bwd(const float* dy, const float* dhT, const float* 
                                 const float* c0, const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, long T, long B,
                                 long H, long Kp, long Gp, float* ws, int* err, hipStream_t s);
 
+// the 2-D partitioned persistent BPTT (round 4): lstm_bptt2.hip
+bool nnl_lstm_bptt2_ok(long B, long H, long Gp);
+size_t nnl_lstm_bptt2_ws_floats(long T, long B, long H, long Gp);
+hipError_t nnl_lstm_bptt2(const float* dy, const float* dhT, const float* dcT, const float* gates, const float* cy, const float* c0,
+                          const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, long T, long B, long H, long Gp,
+                          float* ws, int* err, hipStream_t s);
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -37,6 +44,8 @@ constexpr int kBlock = 256;
 // must stream all of dgates_{t+1}, 1.2 MB, per step, and its U = 5 output columns leave the 4x4 MFMA chains latency-bound).
 bool persist_fwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 1) != 0; }
 bool persist_bwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 2) != 0; }
+// bit 2 = the 2-D partitioned persistent BPTT (lstm_bptt2.hip; takes precedence over bit 1)
+bool bptt2_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 4) != 0; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -176,6 +185,8 @@ static size_t lstm_ws_floats(const Plan& p, long T, long B, long H) {
     const size_t pn = nnl_lstm_persist_ws_floats(T, p.Hp, p.Gp);
     if (pn > n) n = pn;
   }
+  const size_t p2 = nnl_lstm_bptt2_ws_floats(T, B, H, p.Gp);     // 0 when the shape does not fit that kernel
+  if (p2 > n) n = p2;
   return n;
 }
 
@@ -240,6 +251,12 @@ extern "C" int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT,
   int* counters = (int*)(slabs + (long)p.sb * p.bwd_slab + BH);
   float* dc = dc0;                               // running d loss / d c_{t-1}, ends as dc0
   NnlProfScope prof(NNL_PROF_LSTM, s, 2.0 * T * B * 4.0 * H * H);
+  if (bptt2_enabled() && err_flag != nullptr && nnl_lstm_bptt2_ok(B, H, p.Gp)) {
+    if (nnl_lstm_bptt2(dy, dhT, dcT, gates, cy, c0, w_hh_t_pad, dgates_pad, dh0, dc0, T, B, H, p.Gp, (float*)workspace, err_flag, s) ==
+        hipSuccess)
+      return NNL_OK;
+    (void)hipGetLastError();                     // refused (not co-resident / LDS attribute): nothing ran, the paths below take over
+  }
   if (persist_bwd_enabled() && err_flag != nullptr && nnl_lstm_persist_ok(B, H, p.Hp, p.Gp)) {
     if (nnl_lstm_persist_bwd(dy, dhT, dcT, gates, cy, c0, w_hh_t_pad, dgates_pad, dh0, dc0, T, B, H, p.Hp, p.Gp, (float*)workspace,
                              err_flag, s) == hipSuccess)

@@ -214,7 +214,7 @@ def test_embedding_rowmask_bit_exact_and_grad():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('fused_bwd,persist', [('0', '1'), ('1', '0'), ('0', '3'), ('0', '0')])
+@pytest.mark.parametrize('fused_bwd,persist', [('0', '1'), ('1', '0'), ('0', '3'), ('0', '0'), ('0', '5')])
 def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, persist, monkeypatch):
     """BASELINE-size layer (bs 64, bptt 70, 1150 -> 1150) on every recurrence path: the persistent cooperative kernels
     (lstm_persist.hip: 230 workgroups exchange h_t / dgates_t through per-timestep slots and meet at a grid barrier per step —
@@ -225,7 +225,7 @@ def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, pe
     from neuralnetworklibrary_amd import ops_text
     from neuralnetworklibrary_amd._lib import lib
     monkeypatch.setenv('NNL_LSTM_FUSED_BWD', fused_bwd)       # '1': the (slower) fused backward step is kept tested too
-    monkeypatch.setenv('NNL_LSTM_PERSIST', persist)           # 1: persistent forward (default); 3: + persistent BPTT; 0: per-timestep
+    monkeypatch.setenv('NNL_LSTM_PERSIST', persist)           # 1: persistent forward; 3: + first persistent BPTT; 5: + 2-D partitioned BPTT (lstm_bptt2.hip); 0: per-timestep
     lib.nnl_reload_env()
     T, B, I, H = 70, 64, 1150, 1150
     g = torch.Generator().manual_seed(3)
@@ -255,6 +255,53 @@ def test_lstm_full_size_recurrence_vs_torch_and_bitwise_repeatable(fused_bwd, pe
     assert_close(runs[0][3], ref.weight_hh_l0.grad, 1e-3, 1e-4 * ref.weight_hh_l0.grad.abs().max().item(), 'dW_hh')
     from neuralnetworklibrary_amd import ops
     ops.raise_if_index_error()                                 # (also carries the persistent kernel's barrier time-out flag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T,B,I,H', [(12, 20, 48, 100), (70, 64, 1150, 400), (9, 64, 32, 32), (5, 33, 64, 256)])
+def test_lstm_bptt2_partition_shapes_vs_torch_fp64(T, B, I, H, monkeypatch):
+    """The 2-D partitioned persistent BPTT (lstm_bptt2.hip, NNL_LSTM_PERSIST bit 2) on other shapes than the headline's: the
+    last AWD-LSTM layer (1150 -> 400), ragged batches (B < 64: masked rows), H not a multiple of the column tile, a k range
+    that leaves the padded gate columns to the last slice.  Against torch's LSTM in fp64, bitwise repeatable, and the planner's
+    partition must cover the problem."""
+    import ctypes
+    from neuralnetworklibrary_amd import ops_text, ops
+    from neuralnetworklibrary_amd._lib import lib
+    out5 = (ctypes.c_int32 * 5)()
+    assert lib.nnl_debug_lstm_bptt2_plan(B, H, out5) == 1
+    KG, NG, Ks, Ns, NT = list(out5)
+    Gp = int(lib.nnl_lstm_padded_gates(H))
+    assert KG * NG <= 256 and KG * Ks == Gp and NG * Ns >= H and (NG - 1) * Ns < H and 16 * NT >= Ns
+    monkeypatch.setenv('NNL_LSTM_PERSIST', '5')
+    lib.nnl_reload_env()
+    g = torch.Generator().manual_seed(T + H)
+    x = torch.randn(T, B, I, generator=g) * 0.5
+    w_ih, w_hh = torch.randn(4 * H, I, generator=g) / I ** 0.5, torch.randn(4 * H, H, generator=g) / H ** 0.5
+    b_ih, b_hh = torch.randn(4 * H, generator=g) * 0.1, torch.randn(4 * H, generator=g) * 0.1
+    h0, c0 = torch.randn(1, B, H, generator=g) * 0.1, torch.randn(1, B, H, generator=g) * 0.1
+    wy, wc, wh = torch.randn(T, B, H, generator=g), torch.randn(1, B, H, generator=g), torch.randn(1, B, H, generator=g)
+    dev = lambda t: t.to('cuda')
+    runs = []
+    for _ in range(2):
+        xg, wg, hg, cg = dev(x).requires_grad_(True), dev(w_hh).requires_grad_(True), dev(h0).requires_grad_(True), dev(c0).requires_grad_(True)
+        y, (hT, cT) = ops_text.lstm_layer(xg, hg, cg, dev(w_ih), wg, dev(b_ih), dev(b_hh))
+        ((y * dev(wy)).sum() + (cT * dev(wc)).sum() + (hT * dev(wh)).sum()).backward()
+        runs.append((y.detach().clone(), xg.grad.clone(), wg.grad.clone(), hg.grad.clone(), cg.grad.clone()))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b), 'bitwise repeatable'
+    ref = torch.nn.LSTM(I, H).double()
+    with torch.no_grad():
+        ref.weight_ih_l0.copy_(w_ih); ref.weight_hh_l0.copy_(w_hh); ref.bias_ih_l0.copy_(b_ih); ref.bias_hh_l0.copy_(b_hh)
+    xd, hd0, cd0 = x.double().requires_grad_(True), h0.double().requires_grad_(True), c0.double().requires_grad_(True)
+    yd, (hd, cd) = ref(xd, (hd0, cd0))
+    ((yd * wy.double()).sum() + (cd * wc.double()).sum() + (hd * wh.double()).sum()).backward()
+    tol = lambda t: 1e-4 * t.abs().max().item()
+    assert_close(runs[0][0], yd.detach(), 1e-4, 1e-5, 'y')
+    assert_close(runs[0][1], xd.grad, 1e-3, tol(xd.grad), 'dx')
+    assert_close(runs[0][2], ref.weight_hh_l0.grad, 1e-3, tol(ref.weight_hh_l0.grad), 'dW_hh')
+    assert_close(runs[0][3], hd0.grad, 1e-3, tol(hd0.grad), 'dh0')
+    assert_close(runs[0][4], cd0.grad, 1e-3, tol(cd0.grad), 'dc0')
+    ops.raise_if_index_error()
 
 
 @pytest.mark.gpu
