@@ -39,13 +39,14 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// NNL_LSTM_PERSIST: bit 0 = persistent forward, bit 1 = persistent backward.  Default 1: the persistent BPTT kernel is correct
-// (tests/test_text.py runs it) but measured slower than the per-timestep pair at H = 1150 (42 vs 25 us per step: every workgroup
-// must stream all of dgates_{t+1}, 1.2 MB, per step, and its U = 5 output columns leave the 4x4 MFMA chains latency-bound).
-bool persist_fwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 1) != 0; }
-bool persist_bwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 2) != 0; }
+// NNL_LSTM_PERSIST: bit 0 = persistent forward, bit 1 = the first persistent backward, bit 2 = the 2-D partitioned persistent
+// backward (lstm_bptt2.hip).  Default 5.  The first persistent BPTT kernel is correct (tests/test_text.py runs it) but measured
+// slower than the per-timestep pair at H = 1150 (42 vs 20-25 us per step: every workgroup must stream all of dgates_{t+1}, 1.2 MB,
+// per step, and its U = 5 output columns leave the 4x4 MFMA chains latency-bound); the 2-D partition takes 15-16 us.
+bool persist_fwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 1) != 0; }
+bool persist_bwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 2) != 0; }
 // bit 2 = the 2-D partitioned persistent BPTT (lstm_bptt2.hip; takes precedence over bit 1)
-bool bptt2_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 1) & 4) != 0; }
+bool bptt2_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 4) != 0; }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 

@@ -34,5 +34,5 @@ for i in range(8):
     if i >= 2:
         best = min(best, ev[0].elapsed_time(ev[1]))
 print('H %d B %d T %d persist %s dbg %s kg/ng %s/%s: %.3f ms = %.1f us per step  (flag %d, ws %.0f MB)' % (
-    H, B, T, os.environ.get('NNL_LSTM_PERSIST', '1'), os.environ.get('NNL_LSTM_BPTT2_DBG', '0'), os.environ.get('NNL_LSTM_BPTT2_KG', '-'),
+    H, B, T, os.environ.get('NNL_LSTM_PERSIST', '5'), os.environ.get('NNL_LSTM_BPTT2_DBG', '0'), os.environ.get('NNL_LSTM_BPTT2_KG', '-'),
     os.environ.get('NNL_LSTM_BPTT2_NG', '-'), best, best / T * 1e3, int(flag.item()), wsb / 1e6))

@@ -4,7 +4,6 @@ timeout -k 10 400 python -m pytest tests/test_text.py -x -q -m gpu -k "bptt2 or 
 [ $rc -eq 0 ] || exit $rc
 export NNL_LSTM_PERSIST=5
 NNL_LSTM_PERSIST=1 timeout -k 10 100 python tools/bench_bptt.py 2>/dev/null
-for cfg in "16 16" "9 24" "12 18" "18 12" "8 24" "16 15"; do set -- $cfg; NNL_LSTM_BPTT2_KG=$1 NNL_LSTM_BPTT2_NG=$2 timeout -k 10 100 python tools/bench_bptt.py 2>/dev/null; done
-for d in 1 2 3; do NNL_LSTM_BPTT2_DBG=$d NNL_LSTM_BPTT2_KG=16 NNL_LSTM_BPTT2_NG=16 timeout -k 10 100 python tools/bench_bptt.py 2>/dev/null; done
-NNL_LSTM_PERSIST=1 timeout -k 10 100 python tools/bench_bptt.py 400 2>/dev/null
-timeout -k 10 100 python tools/bench_bptt.py 400 2>/dev/null
+for pb in 16 8 16 8; do echo PB=$pb; NNL_LSTM_BPTT2_PB=$pb timeout -k 10 100 python tools/bench_bptt.py 2>/dev/null; NNL_LSTM_BPTT2_PB=$pb NNL_LSTM_BPTT2_DBG=12 timeout -k 10 100 python tools/bench_bptt.py 2>/dev/null; done
+for pb in 16 8; do NNL_LSTM_BPTT2_PB=$pb timeout -k 10 100 python tools/bench_bptt.py 400 2>/dev/null; done
+for m in 1 5 1 5; do NNL_LSTM_PERSIST=$m timeout -k 10 200 python tools/bench_heads.py lm --steps 20 2>/dev/null | tail -1 | cut -c1-200; done
