@@ -398,6 +398,8 @@ int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const floa
 /* The partition (KG x NG workgroups, k-slice Ks, column slice Ns, NT column tiles -> out5) the 2-D persistent BPTT kernel
  * (csrc/lstm_bptt2.hip) would use for this shape; returns 0 when the shape does not fit it.  Host-only. */
 int nnl_debug_lstm_bptt2_plan(int64_t B, int64_t H, int32_t* out5);
+/* The same for the 2-D persistent forward kernel (csrc/lstm_fwd2.hip): KG, NG, Ks, Us (units per column group), NT. */
+int nnl_debug_lstm_fwd2_plan(int64_t B, int64_t H, int32_t* out5);
 
 /* nn.MSELoss(reduction='mean') — `loss_func_dict['cont']` (General/Learner.py:20), the loss of the collaborative-filtering and
  * structured-data heads: *loss = mean((pred - target)^2) over n fp32 elements (one launch up to 65 536 samples, fixed-order sum);

@@ -99,6 +99,7 @@ SIGNATURES = {
     'nnl_lstm_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_lstm_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_debug_lstm_bptt2_plan': (C.c_int, [i64, i64, c_p]),
+    'nnl_debug_lstm_fwd2_plan': (C.c_int, [i64, i64, c_p]),
     'nnl_embedding_rowmask_fwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, c_p, c_p]),
     'nnl_embedding_rowmask_bwd_workspace_bytes': (sz, [i64]),
     'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p, sz, c_p]),

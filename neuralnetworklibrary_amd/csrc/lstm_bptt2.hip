@@ -23,7 +23,9 @@
 // loads until the tag equals the step it waits for: the data is its own flag — no drain, no counter, no barrier; a hand-over costs
 // one store -> load latency.  Granules of different steps rotate through 4 slots: a workgroup that is in phase A of step s + 2
 // implies every workgroup has finished phase B of step s (every unit's four gate columns feed some k slice of every column
-// group), so a slot is never overwritten while somebody may still read it; a consumer that does see a foreign tag keeps polling.
+// group), so a slot is never overwritten while somebody may still read it.  The one exception are workgroups that wait for
+// nothing (a k slice that lies entirely in the zero padding, no valid batch rows): they may run many steps ahead — but everything
+// they ever publish is zero, so a consumer accepts any tag >= the step it waits for (an older tag: keep polling).
 // Polls are bounded: on time-out the kernel sets *err = 2 and carries on to the end (no workgroup ever blocks another: the grid
 // always drains).  The exchange buffers must be ZERO on entry (tag 0 = nothing yet; steps count from 1).
 // Workgroups that share a k slice poll the same granules: they are placed on one XCD (blocks b and b + 8 share an XCD).
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-          const bool b4 = (unsigned)c[j][0][1] != tag || (unsigned)c[j][0][3] != tag || (unsigned)c[j][1][1] != tag || (unsigned)c[j][1][3] != tag;
+          const bool b4 = (unsigned)c[j][0][1] < tag || (unsigned)c[j][0][3] < tag || (unsigned)c[j][1][1] < tag || (unsigned)c[j][1][3] < tag;
           bad |= b4 && live(g0 + j);
         }
         return __builtin_amdgcn_ballot_w64(bad && !any_tag) != 0;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
           one[1] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)(off == 0xFFFFFFFFu ? off : off + 16), 0, 16));
         };
         auto stale1 = [&]() {
-          const bool b4 = (unsigned)one[0][1] != tag || (unsigned)one[0][3] != tag || (unsigned)one[1][1] != tag || (unsigned)one[1][3] != tag;
+          const bool b4 = (unsigned)one[0][1] < tag || (unsigned)one[0][3] < tag || (unsigned)one[1][1] < tag || (unsigned)one[1][3] < tag;
           return __builtin_amdgcn_ballot_w64(b4 && lv && !any_tag) != 0;
         };
         fetch1();
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
         auto stale8 = [&]() {
           bool bad = false;
 #pragma unroll
-          for (int j = 0; j < kPB; ++j) bad |= tag_of(v[j]) != tag;
+          for (int j = 0; j < kPB; ++j) bad |= tag_of(v[j]) < tag;
           return __builtin_amdgcn_ballot_w64(bad && !any_tag) != 0;
         };
         fetch8();
