@@ -110,6 +110,19 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
   return NNL_OK;
 }
 
+// one tap, C % 4 == 0 but not a multiple of the k block: the KTAIL instantiation of the 64x64 kernel (igemm_taps.h)
+template <int BK>
+int launch_taps_ktail(IgemmTapsParams p, hipStream_t s) {
+  p.variant = 1;
+  p.epi4 = NNL_ENV_INT("NNL_IGEMM_EPI4", 1);
+  p.grid_m = (int)nnl_cdiv(p.M, 64);
+  p.grid_n = (int)nnl_cdiv(p.Nc, 64);
+  p.cls_tiles = p.grid_m * p.grid_n;
+  hipLaunchKernelGGL((igemm_taps_kernel<64, 64, BK, 2, 2, true, 0, false, 1, true>), dim3((unsigned)(p.grid_m * p.grid_n), 1), dim3(256), 0, s, p);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
 // ---- balanced schedule for the 64x64 taps kernel (see IgemmTapsParams::bal) --------------------------------------------
 // The plan is a pure function of the GEMM shape, so the *_workspace_bytes() query and the launch agree.
 struct BalPlan {
@@ -260,6 +273,15 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
   p.tile_counters = counters;                       // debug builds: the timestamp area lives behind the counters (igemm_taps.h)
 #endif
   if (bn_rows) *bn_rows = 0;
+  if (p.ktail) {
+    const bool dense = p.out_stride == 1 && p.OH == p.P && p.OW == p.Q && p.oh0 == 0 && p.ow0 == 0 && p.ksplit <= 1;
+    if (p.bn_part && dense) {
+      if (bn_rows) *bn_rows = (int)nnl_cdiv(p.M, 64);
+    } else {
+      p.bn_part = nullptr;
+    }
+    return p.C >= 64 ? launch_taps_ktail<32>(p, s) : launch_taps_ktail<16>(p, s);
+  }
   const int forced = NNL_ENV_INT("NNL_IGEMM_TILE", -1);
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
@@ -319,6 +341,15 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
 
 bool taps_ok(long a_elems, long b_elems, int C, int ntaps) {
   return C % 16 == 0 && ntaps <= IGEMM_MAX_TAPS && a_elems * 4 < (1L << 31) && b_elems * 4 < (1L << 32) - 64;
+}
+
+// 1: the tap-table kernel as is; 2: its KTAIL instantiation (one tap, C a multiple of 4 only: NNL_IGEMM_KTAIL=0 sends those shapes
+// back to the first-generation kernel); 0: neither
+int taps_kind(long a_elems, long b_elems, int C, int ntaps) {
+  if (taps_ok(a_elems, b_elems, C, ntaps)) return 1;
+  if (ntaps == 1 && C % 4 == 0 && C >= 32 && a_elems * 4 < (1L << 31) && b_elems * 4 < (1L << 32) - 64 && NNL_ENV_INT("NNL_IGEMM_KTAIL", 1) != 0)
+    return 2;
+  return 0;
 }
 
 __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K, int RS, int C) {
@@ -1073,8 +1104,9 @@ extern "C" int nnl_conv2d_fwd_pre(const float* x, const float* w, const float* b
     if (st == NNL_OK && stats) *bn_rows = wmode >= 2 ? nnl_wino2_bn_rows(g->N, g->H, g->W) : nnl_wino_bn_rows(g->N, g->H, g->W);
     return st;
   }
-  if (taps_ok(a_elems, b_elems, g->C, g->R * g->S)) {
+  if (const int tk = taps_kind(a_elems, b_elems, g->C, g->R * g->S)) {
     IgemmTapsParams q{};
+    q.ktail = tk == 2;
     q.a = x; q.b = w; q.y = y; q.bias = bias; q.add = nullptr;
     q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
     q.H = g->H; q.W = g->W; q.C = g->C; q.P = g->P; q.Q = g->Q;
@@ -1184,8 +1216,10 @@ extern "C" int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx,
     wq.u_pre = u;
     return wino_mode_launch(wmode, wq, workspace, workspace_bytes, tile_counters, kTileCounters, s);
   }
-  if (taps_ok(a_elems, b_elems, g->K, g->R * g->S) && (g->stride == 1 || g->stride == 2)) {
+  const int tk = taps_kind(a_elems, b_elems, g->K, g->R * g->S);
+  if (tk && (g->stride == 1 || g->stride == 2)) {
     IgemmTapsParams q{};
+    q.ktail = tk == 2;
     q.a = dy; q.b = wt; q.y = dx; q.bias = nullptr; q.add = addend;
     q.a_bytes = (unsigned)(a_elems * 4); q.b_bytes = (unsigned)(b_elems * 4);
     q.H = g->P; q.W = g->Q; q.C = g->K;                     // gathered tensor = dy [N][P][Q][K]

@@ -63,6 +63,7 @@ struct IgemmTapsParams {
   // reduce kernel sums (deterministic).  tail rows start at tail_row0 (n_main_tiles is a multiple of grid_n).
   int bal, main_ks, n_main_tiles, tail_slices, tail_row0;
   LstmEpi lstm;                        // EPI != 0 instantiations only
+  int ktail;                           // 1: launch the KTAIL instantiation (one tap, C % 4 == 0 but C % 16 != 0; conv2d.hip: taps_kind)
   int epi4;                            // 1: row-major float4 epilogue of the unsplit 64x64 tile (dense outputs; NNL_IGEMM_EPI4)
   int variant;                         // 1: PIPE instantiation of the 64x64 kernel (A/B: tools/bench_conv.py --ab NNL_IGEMM_VARIANT=0,1)
   float* main_out; long main_slab_stride;      // main_ks > 1: slabs [main_ks][tail_row0][Nc]
@@ -117,8 +118,13 @@ __device__ __forceinline__ float nnl_sigmoid(float x) { return 1.f / (1.f + expf
 // request then has two iterations (~2.5 us with three co-resident workgroups) to come back instead of one: with 64-channel
 // layers almost every A tile contains a first-touch L2 miss (12 % of the lines, 32 lines per wave and tile), and the
 // co-resident workgroups of a CU, phase-locked by the shared MFMA pipe, all wait for theirs at the same time.
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0, bool DMA = false, int PF = 1>
+// KTAIL = true (register staging, one tap: Linear / 1x1 layers whose channel count is a multiple of 4 but not of BK — the tabular
+// MLP's 204 / 1000 / 500 columns; round 4): the k loop runs over ceil(C / BK) tiles and, in the last one, the lanes whose 16-B
+// chunk starts at a channel >= C fetch from an out-of-range offset (zeros) on BOTH operands, so neither the next row's data nor
+// a NaN in it can reach the sum.  Those shapes ran on the first-generation kernel before (23-38 TF/s against 60 here).
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int EPI = 0, bool DMA = false, int PF = 1, bool KTAIL = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)) ? 3 : 4) void igemm_taps_kernel(const IgemmTapsParams p) {
+  static_assert(!KTAIL || (!DMA && EPI == 0 && PF == 1), "the k tail is masked in the register-staging loads");
   static_assert(PF == 1 || (PF == 2 && !DMA), "PF = 2 is a register-staging variant");
   static_assert(EPI == 0 || (BM == 64 && BN == 64), "the LSTM epilogue is written for the 64x64 tile");
   static_assert(WGM * WGN == 4 && BK % 8 == 0, "config");
@@ -268,10 +274,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_src, NNL_LDSP(dst + BM * BK), 16, (int)b_off[i], (int)b_tap + c0 * 4, 0, 0);
       }
     } else {
+      const bool okc = !KTAIL || c0 + kc * 4 < p.C;          // (KTAIL: false only in the last k tile, for the chunks beyond C)
 #pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, a_voff[i], (unsigned)c0 * 4u);
+      for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, okc ? a_voff[i] : 0xFFFFFFFFu, (unsigned)c0 * 4u);
 #pragma unroll
-      for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, b_off[i], b_tap + (unsigned)c0 * 4u);
+      for (int i = 0; i < PB; ++i) rb[i] = buf_load4(rb_src, okc ? b_off[i] : 0xFFFFFFFFu, b_tap + (unsigned)c0 * 4u);
     }
   };
   auto store_tile = [&](int buf) {
@@ -384,7 +391,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)
   };
 
   // ---- k loop: scalar state (tap, channel offset); the body has no branches ----
-  const int csteps = p.C / BK;
+  const int csteps = KTAIL ? (p.C + BK - 1) / BK : p.C / BK;
   const int nk_all = ntaps * csteps;
   int kt0 = 0, nk = nk_all;
   if (partial) {                               // split-K: this workgroup reduces k tiles [kt0, kt0 + nk)

@@ -566,7 +566,8 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             g_w, dyn_w, wn_w = g, dyn, wn                   # (the weight gradient keeps the unpadded operands)
-            if g.K % 16 != 0 and g.K >= 32 and os.environ.get('NNL_DGRAD_PAD16', '1') != '0':
+            ktail = g.R == 1 and g.S == 1 and g.K % 4 == 0 and os.environ.get('NNL_IGEMM_KTAIL', '1') != '0'     # the tap kernel masks the k tail itself
+            if g.K % 16 != 0 and g.K >= 32 and not ktail and os.environ.get('NNL_DGRAD_PAD16', '1') != '0':
                 # dgrad reduces over K: the tap-table kernel needs K % 16 == 0 (RetinaNet's 36- / 180-channel output convs would
                 # fall back to the first-generation kernel, ~2.5x slower); zero channels cost one copy of dy
                 padk = 16 - g.K % 16

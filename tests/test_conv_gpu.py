@@ -44,6 +44,13 @@ CASES = [
     (16, 256, 8, 8, 180, 3, 1, 1, True, 2),
     (1, 256, 64, 64, 180, 3, 1, 1, True, 2),
     (3, 32, 9, 7, 24, 3, 1, 1, True, 2),
+    # one tap, C % 4 == 0 but not a multiple of the k block: the KTAIL instantiation (forward: C, dgrad: K) — round 4
+    (1024, 204, 1, 1, 1000, 1, 1, 0, True, True),   # the tabular MLP's layers as 1x1 convolutions
+    (1024, 1000, 1, 1, 500, 1, 1, 0, True, True),
+    (1024, 500, 1, 1, 4, 1, 1, 0, True, False),
+    (70, 36, 1, 1, 44, 1, 1, 0, False, False),      # ragged tiles, k tail of 4 in a 32-wide block
+    (2, 40, 9, 7, 100, 1, 1, 0, True, True),        # a 1x1 convolution over pixels
+    (3, 52, 8, 8, 60, 1, 2, 0, True, False),        # 1x1 / stride 2
 ]
 
 
