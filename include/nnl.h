@@ -350,6 +350,14 @@ int nnl_tab_scatter_bwd(const int64_t* xcat, const int32_t* card, const int32_t*
                         const float* cont_mask, const float* dout, float* dtab_flat, int64_t dtab_elems,
                         float* dcont, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward WITHOUT a sort, in one launch (round 4; embedding widths <= 32): block b < n_scan_blocks owns the flat elements
+ * blk_first[b] .. +255 of column blk_col[b]'s [card][dim] gradient and scans that column's bs indices in sample order (the
+ * summation order of nnl_tab_scatter_bwd's deterministic path); every element of dtab_flat is written (no zero fill needed), the
+ * continuous columns' gradient rides along.  dout may have any row stride ld_out >= cat_width + n_cont. */
+int nnl_tab_scan_bwd(const int64_t* xcat, const int32_t* card, const int32_t* dim, const int32_t* col_off,
+                     const int64_t* grad_off, const float* row_mask, const float* cont_mask, const float* dout,
+                     float* dtab_flat, float* dcont, const int32_t* blk_col, const int32_t* blk_first, int32_t n_scan_blocks,
+                     int32_t max_dim, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out, void* stream);
 
 /* ---- K6: fused RetinaNet detection loss (anchor matching + focal + smooth-L1) -----------------------------
  * Replaces SSD_loss.__call__ and everything it calls per image (Applications/Vision.py:1620-1644 -> ssd1 :1568-1605,

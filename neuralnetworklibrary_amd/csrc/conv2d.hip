@@ -229,7 +229,11 @@ int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counte
   p.tail_out = ws + pl.main_floats; p.tail_slab_stride = (long)(p.M - pl.tail_row0) * p.Nc;
   p.tile_counters = (pl.bm == 64) ? counters : nullptr;      // in-kernel fix-up of the split tiles (64x64 tile only)
   const unsigned grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
-  if (pl.bk == 32 && taps_dma(32, p))
+  if (p.ktail && pl.bk == 32)
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, true, 0, false, 1, true>), dim3(grid), dim3(256), 0, s, p);
+  else if (p.ktail)
+    hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, true, 0, false, 1, true>), dim3(grid), dim3(256), 0, s, p);
+  else if (pl.bk == 32 && taps_dma(32, p))
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 32, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
   else if (pl.bk != 32 && taps_dma(16, p))
     hipLaunchKernelGGL((igemm_taps_kernel<64, 64, 16, 2, 2, false, 0, true>), dim3(grid), dim3(256), 0, s, p);
@@ -275,10 +279,24 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
   if (bn_rows) *bn_rows = 0;
   if (p.ktail) {
     const bool dense = p.out_stride == 1 && p.OH == p.P && p.OW == p.Q && p.oh0 == 0 && p.ow0 == 0 && p.ksplit <= 1;
-    if (p.bn_part && dense) {
+    float* const bn_part_k = p.bn_part;
+    p.bn_part = nullptr;
+    if (ws != nullptr && dense) {
+      // few, long tiles (1024 x 500 x 1000: 128 workgroups of 32 k steps): the balanced schedule's k slices fill the chip
+      const BalPlan pl = plan_balance(p.M, p.Nc, (int)nnl_cdiv(p.C, 32) * 32, 1);
+      if (pl.on && ws_bytes >= (pl.main_floats + pl.tail_floats) * sizeof(float)) {
+        const long tiles = nnl_cdiv(p.M, pl.bm) * nnl_cdiv(p.Nc, 64);
+        int* const cnt = tiles <= kTileCounters ? counters : nullptr;
+        if (bn_part_k && cnt != nullptr) {
+          p.bn_part = bn_part_k;
+          if (bn_rows) *bn_rows = (int)nnl_cdiv(p.M, 64);
+        }
+        return launch_balanced(p, pl, (float*)ws, cnt, s);
+      }
+    }
+    if (bn_part_k && dense) {
+      p.bn_part = bn_part_k;
       if (bn_rows) *bn_rows = (int)nnl_cdiv(p.M, 64);
-    } else {
-      p.bn_part = nullptr;
     }
     return p.C >= 64 ? launch_taps_ktail<32>(p, s) : launch_taps_ktail<16>(p, s);
   }
@@ -1040,7 +1058,9 @@ extern "C" int nnl_debug_conv_plan_times(int N, int H, int W, int Cin, int Nc, d
 extern "C" size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g) {
   if (!g || check_geom(g, "conv2d_fwd_workspace_bytes")) return 0;
   const long a_elems = (long)g->N * g->H * g->W * g->C, b_elems = (long)g->K * g->R * g->S * g->C;
-  if (!taps_ok(a_elems, b_elems, g->C, g->R * g->S)) return 0;
+  const int tk = taps_kind(a_elems, b_elems, g->C, g->R * g->S);
+  if (!tk) return 0;
+  if (tk == 2) return balance_workspace_bytes((long)g->N * g->P * g->Q, g->K, (int)nnl_cdiv(g->C, 32) * 32, 1);
   size_t b = balance_workspace_bytes((long)g->N * g->P * g->Q, g->K, g->C, g->R * g->S);
   if (const int wm = wino_mode(g->N, g->H, g->W, g->C, g->K, g->R, g->S, g->stride, g->pad)) {
     const size_t wb = wino_mode_workspace(wm, g->N, g->H, g->W, g->C, g->K);
@@ -1052,7 +1072,9 @@ extern "C" size_t nnl_conv2d_fwd_workspace_bytes(const nnl_conv_geom_t* g) {
 extern "C" size_t nnl_conv2d_dgrad_workspace_bytes(const nnl_conv_geom_t* g) {
   if (!g || check_geom(g, "conv2d_dgrad_workspace_bytes") || g->stride != 1) return 0;
   const long a_elems = (long)g->N * g->P * g->Q * g->K, b_elems = (long)g->C * g->R * g->S * g->K;
-  if (!taps_ok(a_elems, b_elems, g->K, g->R * g->S)) return 0;
+  const int tk = taps_kind(a_elems, b_elems, g->K, g->R * g->S);
+  if (!tk) return 0;
+  if (tk == 2) return balance_workspace_bytes((long)g->N * g->H * g->W, g->C, (int)nnl_cdiv(g->K, 32) * 32, 1);
   size_t b = balance_workspace_bytes((long)g->N * g->H * g->W, g->C, g->K, g->R * g->S);
   if (const int wm = wino_mode(g->N, g->P, g->Q, g->K, g->C, g->R, g->S, g->stride, g->pad)) {
     const size_t wb = wino_mode_workspace(wm, g->N, g->P, g->Q, g->K, g->C);

@@ -1119,6 +1119,15 @@ class TabularPlan:
         self.col_table = t(np.repeat(np.arange(self.ncat), dim), torch.int32)
         self.row_table = t(np.repeat(np.arange(self.ncat), card), torch.int32)
         self.flags = torch.zeros(self.total_rows, dtype=torch.int32, device=dev)
+        # sort-free backward (nnl_tab_scan_bwd): 256 flat gradient elements of ONE column per block
+        self.max_dim = max(dim) if dim else 0
+        blk_col, blk_first = [], []
+        for j, n in enumerate(sizes):
+            for f in range(0, n, 256):
+                blk_col.append(j)
+                blk_first.append(f)
+        self.n_scan_blocks = len(blk_col)
+        self.blk_col, self.blk_first = t(blk_col or [0], torch.int32), t(blk_first or [0], torch.int32)
 
     @staticmethod
     def for_weights(weights, cached=None):
@@ -1160,15 +1169,23 @@ class _TabEmbedConcat(torch.autograd.Function):
     def backward(ctx, dout):
         xcat, row_mask, cont_mask = ctx.saved_tensors
         plan, n_cont = ctx.plan, ctx.n_cont
-        dout = _f32c(dout)
         bs = xcat.shape[0]
         flat = torch.empty(max(plan.grad_elems, 1), dtype=torch.float32, device=dout.device)
         dcont = torch.empty(bs, n_cont, dtype=torch.float32, device=dout.device) if (n_cont and ctx.needs_input_grad[1]) else None
-        wsb = int(lib.nnl_tab_scatter_bwd_workspace_bytes(bs, plan.ncat))            # sample-order (deterministic) scatter-add
-        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dout.device)
-        check(lib.nnl_tab_scatter_bwd(ptr(xcat), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off), ptr(plan.col_table),
-                                      ptr(plan.grad_off), ptr(row_mask), ptr(cont_mask), ptr(dout), ptr(flat), plan.grad_elems,
-                                      ptr(dcont), bs, plan.ncat, plan.cat_width, n_cont, dout.shape[1], ptr(ws), wsb, stream()))
+        if plan.ncat and bs and 0 < plan.max_dim <= 32 and os.environ.get('NNL_TAB_SCAN', '1') != '0':
+            # one launch, no sort, no zero fill; a row-strided gradient (the slice of a channel-padded buffer) is read in place
+            if not (dout.dtype == torch.float32 and dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= dout.shape[1]):
+                dout = _f32c(dout)
+            check(lib.nnl_tab_scan_bwd(ptr(xcat), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off), ptr(plan.grad_off), ptr(row_mask),
+                                       ptr(cont_mask), ptr(dout), ptr(flat), ptr(dcont), ptr(plan.blk_col), ptr(plan.blk_first),
+                                       plan.n_scan_blocks, plan.max_dim, bs, plan.ncat, plan.cat_width, n_cont, dout.stride(0), stream()))
+        else:
+            dout = _f32c(dout)
+            wsb = int(lib.nnl_tab_scatter_bwd_workspace_bytes(bs, plan.ncat))            # sample-order (deterministic) scatter-add
+            ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=dout.device)
+            check(lib.nnl_tab_scatter_bwd(ptr(xcat), ptr(plan.card), ptr(plan.dim), ptr(plan.col_off), ptr(plan.col_table),
+                                          ptr(plan.grad_off), ptr(row_mask), ptr(cont_mask), ptr(dout), ptr(flat), plan.grad_elems,
+                                          ptr(dcont), bs, plan.ncat, plan.cat_width, n_cont, dout.shape[1], ptr(ws), wsb, stream()))
         grads, o = [], 0
         for n, shp in zip(plan.grad_sizes, plan.shapes):
             grads.append(flat[o:o + n].view(shp))

@@ -255,3 +255,35 @@ def test_g16_rossmann_curve_hip_learner_every_step_within_1e3():
     with torch.no_grad():
         pred = net(batches[0][0][0].to(DEV), batches[0][0][1].to(DEV))
     assert_close(pred[:64], g['eval_pred0.f32'], 1e-3, 1e-3, 'eval-mode prediction after the 20 steps')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bs,cards,n_cont,pad', [(1024, [1116, 5, 4, 13, 53, 13, 4, 8, 32, 23] + [10] * 6, 14, 1), (300, [7, 300, 2], 0, 0),
+                                                 (257, [40, 3], 5, 3)])
+def test_tabular_backward_without_sort_vs_the_sorted_path(bs, cards, n_cont, pad, monkeypatch):
+    """nnl_tab_scan_bwd (one launch: every (table row, component) scans its column and adds in plain sample order — the order
+    of torch's CPU embedding backward) against the rank-sort + segment-sum path it replaces by default (several sample slots per
+    row + a fixed tree for rows with many samples: another fixed order): equal to rounding, each bitwise repeatable; also with a
+    row-strided upstream gradient (the slice of a channel-padded buffer, read in place) and ragged sizes."""
+    from neuralnetworklibrary_amd import ops
+    from neuralnetworklibrary_amd.Applications.StructuredData import embedding_dim
+    g = torch.Generator().manual_seed(bs)
+    dims = [embedding_dim(c) for c in cards]
+    xcat = torch.stack([torch.randint(0, c, (bs,), generator=g) for c in cards], 1).to(DEV)
+    cont = torch.randn(bs, n_cont, generator=g).to(DEV) if n_cont else None
+    row_masks = (torch.rand(len(cards), bs, generator=g) > 0.1).float().div(0.9).to(DEV)
+    cont_mask = (torch.rand(bs, n_cont, generator=g) > 0.2).float().div(0.8).to(DEV) if n_cont else None
+    ld = sum(dims) + n_cont
+    dfull = torch.randn(bs, ld + pad, generator=g).to(DEV)
+    outs = []
+    for scan in ('0', '1', '1'):
+        monkeypatch.setenv('NNL_TAB_SCAN', scan)
+        ws = [(torch.randn(c, d, generator=torch.Generator().manual_seed(7 + i)) * 0.1).to(DEV).requires_grad_(True) for i, (c, d) in enumerate(zip(cards, dims))]
+        cg = cont.clone().requires_grad_(True) if n_cont else None
+        out, _ = ops.tab_embed_concat(xcat, ws, row_masks, cg, cont_mask, None)
+        out.backward(dfull[:, :ld])                       # a view with row stride ld + pad
+        outs.append([w.grad.clone() for w in ws] + ([cg.grad.clone()] if n_cont else []))
+    for a, b, c in zip(*outs):
+        assert torch.equal(b, c), 'the scan path is bitwise repeatable'
+        assert_close(b, a, 1e-5, 1e-6 * a.abs().max().item(), 'scan vs sorted')
+    ops.raise_if_index_error()
