@@ -359,6 +359,16 @@ int nnl_tab_scan_bwd(const int64_t* xcat, const int32_t* card, const int32_t* di
                      float* dtab_flat, float* dcont, const int32_t* blk_col, const int32_t* blk_first, int32_t n_scan_blocks,
                      int32_t max_dim, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out, void* stream);
 
+/* nn.Linear with 1 - 4 output features (the last layer of FullyConnectedNet, General/Layers.py:146 — the tabular regression head):
+ * y [M,N] = x [M,K] (row stride ldx) w[N,K]^T + bias.  Backward: dx [M,K] dense, dw [N,K], db [N] (any may be NULL), fixed-order
+ * sums (csrc/linear_small.hip). */
+int nnl_linear_small_supported(int64_t N);
+int nnl_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int64_t M, int64_t K, int64_t ldx, int64_t N,
+                         void* stream);
+size_t nnl_linear_small_bwd_workspace_bytes(int64_t M, int64_t K, int64_t N);
+int nnl_linear_small_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db, int64_t M, int64_t K,
+                         int64_t ldx, int64_t N, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K6: fused RetinaNet detection loss (anchor matching + focal + smooth-L1) -----------------------------
  * Replaces SSD_loss.__call__ and everything it calls per image (Applications/Vision.py:1620-1644 -> ssd1 :1568-1605,
  * match_anchors_objects :1474-1511, jaccard :234-256, focal_loss_retina :1513-1530, smoothL1_loss_retina :1532-1566).

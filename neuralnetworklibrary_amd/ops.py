@@ -748,12 +748,55 @@ def conv2d_with_bn_stats(x, weight, bias, stride, pad, bn_pivot, grad_slot=None,
     return _Conv2d.apply(x, weight, bias, int(stride), int(pad), False, grad_slot, bn_pivot, give_slot)
 
 
+def _rows_in_place(x):
+    "a 2-D fp32 matrix whose rows are dense (any row stride): usable by the kernels that take a leading dimension"
+    return x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1]
+
+
+class _LinearSmall(torch.autograd.Function):
+    """nn.Linear with 1 - 4 output features (FullyConnectedNet.final_lin of the regression heads, General/Layers.py:146): one wave
+    per row forward, fixed-order column reductions backward (csrc/linear_small.hip) instead of a 64-wide MFMA tile per column."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        require_cuda(x, weight, bias)
+        x = x if _rows_in_place(x) else _f32c(x)
+        w = _f32c(weight)
+        b = None if bias is None else _f32c(bias)
+        M, K = x.shape
+        N = w.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        check(lib.nnl_linear_small_fwd(ptr(x), ptr(w), ptr(b), ptr(y), M, K, x.stride(0) if M > 1 else K, N, stream()))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        M, K = x.shape
+        N = w.shape[0]
+        dy = _f32c(dy)
+        dev = dy.device
+        dx = torch.empty(M, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(N, K, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        db = torch.empty(N, dtype=torch.float32, device=dev) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        wsb = int(lib.nnl_linear_small_bwd_workspace_bytes(M, K, N)) if (dw is not None or db is not None) else 0
+        ws = torch.empty(max(wsb // 4, 1), dtype=torch.float32, device=dev) if wsb else None
+        check(lib.nnl_linear_small_bwd(ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), M, K, x.stride(0) if M > 1 else K, N, ptr(ws), wsb,
+                                       stream()))
+        return dx, dw, db
+
+
 def linear(x, weight, bias=None, relu=False, wgrad_side=False):
     """y = x @ weight.T + bias [+ ReLU] (nn.Linear; reference General/Layers.py:39,146; Text.py:572) on the same
     fp32-MFMA implicit-GEMM kernels: a Linear is the 1x1 convolution of a 1x1 'image' per sample.  Leading dims of x
     are flattened into rows.  wgrad_side: the weight gradient may be computed on the side stream (see _Side above)."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
+    if (not relu and weight.shape[0] <= 4 and x2.is_cuda and x2.shape[0] > 0
+            and os.environ.get('NNL_LINEAR_SMALL', '1') != '0'):
+        return _LinearSmall.apply(x2, weight, bias).reshape(*lead, weight.shape[0])
     _Side.pending_param = weight if (wgrad_side and weight.requires_grad) else None
     y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, int(relu), None, None)[0]
     return y.reshape(*lead, weight.shape[0])

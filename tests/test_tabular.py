@@ -287,3 +287,35 @@ def test_tabular_backward_without_sort_vs_the_sorted_path(bs, cards, n_cont, pad
         assert torch.equal(b, c), 'the scan path is bitwise repeatable'
         assert_close(b, a, 1e-5, 1e-6 * a.abs().max().item(), 'scan vs sorted')
     ops.raise_if_index_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,K,N,pad,bias', [(1024, 500, 1, 0, True), (7, 37, 3, 0, True), (130, 203, 4, 5, False), (65, 64, 2, 0, True)])
+def test_linear_with_few_output_features_vs_torch_fp64(M, K, N, pad, bias):
+    """ops.linear's path for 1 - 4 output features (FullyConnectedNet.final_lin of the regression heads; csrc/linear_small.hip):
+    forward and all three gradients against torch in fp64, bitwise repeatable, also on a row-strided input."""
+    from neuralnetworklibrary_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    xfull = torch.randn(M, K + pad, generator=g)
+    w, b = torch.randn(N, K, generator=g) / K ** 0.5, (torch.randn(N, generator=g) if bias else None)
+    dy = torch.randn(M, N, generator=g)
+    xd, wd = xfull[:, :K].double().requires_grad_(True), w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True) if bias else None
+    ref = torch.nn.functional.linear(xd, wd, bd)
+    ref.backward(dy.double())
+    runs = []
+    for _ in range(2):
+        xg = xfull.to(DEV).requires_grad_(True)
+        wg = w.to(DEV).requires_grad_(True)
+        bg = b.to(DEV).requires_grad_(True) if bias else None
+        y = ops.linear(xg[:, :K], wg, bg)
+        y.backward(dy.to(DEV))
+        runs.append([y.detach().clone(), xg.grad[:, :K].clone(), wg.grad.clone()] + ([bg.grad.clone()] if bias else []))
+    for a, c in zip(*runs):
+        assert torch.equal(a, c)
+    tol = lambda t: 1e-5 * t.abs().max().item()
+    assert_close(runs[0][0], ref.detach(), 1e-5, tol(ref.detach()), 'y')
+    assert_close(runs[0][1], xd.grad, 1e-5, tol(xd.grad), 'dx')
+    assert_close(runs[0][2], wd.grad, 1e-5, tol(wd.grad), 'dw')
+    if bias:
+        assert_close(runs[0][3], bd.grad, 1e-5, tol(bd.grad), 'db')
