@@ -359,6 +359,13 @@ int nnl_tab_scan_bwd(const int64_t* xcat, const int32_t* card, const int32_t* di
                      float* dtab_flat, float* dcont, const int32_t* blk_col, const int32_t* blk_first, int32_t n_scan_blocks,
                      int32_t max_dim, int64_t bs, int32_t ncat, int32_t cat_width, int32_t n_cont, int32_t ld_out, void* stream);
 
+/* dst [rows, Cp] = src [rows, C] followed by zero columns (channel padding to the kernels' 4-float granularity, one launch). */
+int nnl_pad_cols(const float* src, float* dst, int64_t rows, int64_t C, int64_t Cp, void* stream);
+/* Two dropout keep masks from ONE uniform draw u [na + nb]: a[i] = (u[i] < keep_a) / keep_a, b[i] = (u[na + i] < keep_b) / keep_b —
+ * the per-sample row masks of EmbeddingDrop and the continuous-input mask of StructuredDataNet (General/Layers.py:75-76,
+ * StructuredData.py:1079: nn.Dropout applied to ones / to the inputs: Bernoulli(keep) / keep). */
+int nnl_keep_masks(const float* u, float* a, int64_t na, float keep_a, float* b, int64_t nb, float keep_b, void* stream);
+
 /* nn.Linear with 1 - 4 output features (the last layer of FullyConnectedNet, General/Layers.py:146 — the tabular regression head):
  * y [M,N] = x [M,K] (row stride ldx) w[N,K]^T + bias.  Backward: dx [M,K] dense, dw [N,K], db [N] (any may be NULL), fixed-order
  * sums (csrc/linear_small.hip). */

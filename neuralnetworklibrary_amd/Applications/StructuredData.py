@@ -136,14 +136,23 @@ class StructuredDataNet(nn.Module):
             return self._injected
         row_masks = cont_mask = None
         p_emb = self.embeddings[0].drop.p if self.n_cat > 0 else 0
-        if self.training and p_emb > 0:          # Layers.py:75-76: drop(ones(len(x))) per column
-            row_masks = keyed_mask((self.n_cat, bs), p_emb, device, sample_dim=1)       # None unless Learner.use_keyed_dropout()
-            if row_masks is None:
-                row_masks = torch.empty(self.n_cat, bs, device=device).bernoulli_(1 - p_emb).div_(1 - p_emb)
         p_cont = self.cont_drop.p
-        if self.training and p_cont > 0 and self.n_cont > 0:
+        want_rows = self.training and p_emb > 0
+        want_cont = self.training and p_cont > 0 and self.n_cont > 0
+        if want_rows:          # Layers.py:75-76: drop(ones(len(x))) per column
+            row_masks = keyed_mask((self.n_cat, bs), p_emb, device, sample_dim=1)       # None unless Learner.use_keyed_dropout()
+        if want_cont:
             cont_mask = keyed_mask((bs, self.n_cont), p_cont, device, sample_dim=0)
-            if cont_mask is None:
+        need_rows, need_cont = want_rows and row_masks is None, want_cont and cont_mask is None
+        if (need_rows or need_cont) and device.type == 'cuda':
+            # both masks from one uniform draw + one launch (Bernoulli(keep) / keep each, as nn.Dropout on ones / on the inputs)
+            a, b = ops.keep_masks((self.n_cat, bs) if need_rows else None, 1 - p_emb, (bs, self.n_cont) if need_cont else None, 1 - p_cont, device)
+            row_masks = a if need_rows else row_masks
+            cont_mask = b if need_cont else cont_mask
+        else:
+            if need_rows:
+                row_masks = torch.empty(self.n_cat, bs, device=device).bernoulli_(1 - p_emb).div_(1 - p_emb)
+            if need_cont:
                 cont_mask = torch.empty(bs, self.n_cont, device=device).bernoulli_(1 - p_cont).div_(1 - p_cont)
         return row_masks, cont_mask
 

@@ -91,6 +91,8 @@ SIGNATURES = {
     'nnl_tab_scatter_bwd_workspace_bytes': (sz, [i64, i32]),
     'nnl_tab_scatter_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, sz, c_p]),
     'nnl_tab_scan_bwd': (C.c_int, [c_p] * 12 + [i32, i32, i64, i32, i32, i32, i32, c_p]),
+    'nnl_pad_cols': (C.c_int, [c_p, c_p, i64, i64, i64, c_p]),
+    'nnl_keep_masks': (C.c_int, [c_p, c_p, i64, f32, c_p, i64, f32, c_p]),
     'nnl_linear_small_supported': (C.c_int, [i64]),
     'nnl_linear_small_fwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p]),
     'nnl_linear_small_bwd_workspace_bytes': (sz, [i64, i64, i64]),

@@ -200,6 +200,28 @@ __global__ __launch_bounds__(256) void tab_scan_bwd_kernel(const int64_t* __rest
   if (mine) dtab[grad_off[j] + f] = acc;
 }
 
+// dst [rows][Cp] = src [rows][C] with zero pad columns (ops._pad_c4: channel counts that are no multiple of 4 — the tabular input
+// width 203, 3-channel images): one launch instead of a fill + a strided copy
+__global__ void pad_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int C, int Cp) {
+  const long total = rows * Cp;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Cp;
+    const int c = (int)(i - r * Cp);
+    dst[i] = c < C ? src[r * C + c] : 0.f;
+  }
+}
+
+// two dropout keep masks from one uniform draw: out[i] = (u[i] < keep) / keep  (the reference draws them with
+// nn.Dropout(ones) / bernoulli_: the same distribution; Layers.py:75-76, StructuredData.py:1079)
+__global__ void keep_masks_kernel(const float* __restrict__ u, float* __restrict__ a, long na, float keep_a, float* __restrict__ b,
+                                  long nb, float keep_b) {
+  const long total = na + nb;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    if (i < na) a[i] = u[i] < keep_a ? 1.f / keep_a : 0.f;
+    else b[i - na] = u[i] < keep_b ? 1.f / keep_b : 0.f;
+  }
+}
+
 int grid_for(long n) {
   long b = nnl_cdiv(n, kBlock);
   if (b > 4096) b = 4096;
@@ -298,6 +320,26 @@ extern "C" int nnl_tab_scan_bwd(const int64_t* xcat, const int32_t* card, const 
   const long cont_blocks = (dcont && n_cont > 0) ? nnl_cdiv(bs * n_cont, 256) : 0;
   hipLaunchKernelGGL(tab_scan_bwd_kernel, dim3((unsigned)(n_scan_blocks + cont_blocks)), dim3(256), 0, s, xcat, card, dim, col_off, grad_off,
                      row_mask, cont_mask, dout, dtab_flat, dcont, blk_col, blk_first, n_scan_blocks, (long)bs, ncat, cat_width, n_cont, ld_out);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_pad_cols(const float* src, float* dst, int64_t rows, int64_t C, int64_t Cp, void* stream) {
+  NNL_CHECK_ARG(rows >= 0 && C > 0 && Cp >= C && Cp < (1 << 24), "pad_cols: bad sizes");
+  if (rows == 0) return NNL_OK;
+  NNL_CHECK_ARG(src && dst, "pad_cols: null pointer");
+  hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for(rows * Cp)), dim3(kBlock), 0, (hipStream_t)stream, src, dst, (long)rows, (int)C, (int)Cp);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
+extern "C" int nnl_keep_masks(const float* u, float* a, int64_t na, float keep_a, float* b, int64_t nb, float keep_b, void* stream) {
+  NNL_CHECK_ARG(na >= 0 && nb >= 0 && (na == 0 || (keep_a > 0.f && keep_a <= 1.f)) && (nb == 0 || (keep_b > 0.f && keep_b <= 1.f)),
+                "keep_masks: bad arguments");
+  if (na + nb == 0) return NNL_OK;
+  NNL_CHECK_ARG(u && (na == 0 || a) && (nb == 0 || b), "keep_masks: null pointer");
+  hipLaunchKernelGGL(keep_masks_kernel, dim3(grid_for(na + nb)), dim3(kBlock), 0, (hipStream_t)stream, u, a, (long)na, keep_a, b, (long)nb,
+                     keep_b);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

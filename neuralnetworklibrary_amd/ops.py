@@ -186,6 +186,11 @@ def _pad_c4(t_nhwc):
     C = t_nhwc.shape[-1]
     if C % 4 == 0:
         return t_nhwc
+    if t_nhwc.is_cuda and t_nhwc.dtype == torch.float32 and t_nhwc.is_contiguous() and not t_nhwc.requires_grad:
+        Cp = C + 4 - C % 4                                # one launch (torch's pad is a fill + a strided copy)
+        out = torch.empty(t_nhwc.shape[:-1] + (Cp,), dtype=torch.float32, device=t_nhwc.device)
+        check(lib.nnl_pad_cols(ptr(t_nhwc), ptr(out), t_nhwc.numel() // C, C, Cp, stream()))
+        return out
     return torch.nn.functional.pad(t_nhwc, (0, 4 - C % 4))
 
 
@@ -1254,6 +1259,17 @@ def _global_lookup_indices(xcat, sync):
     flat = rows.reshape(-1, ncat)
     fill = flat[valid.reshape(-1).to(torch.uint8).argmax()]             # first real row of any rank
     return torch.where(valid.reshape(-1, 1), flat, fill).contiguous()
+
+
+def keep_masks(shape_a, keep_a, shape_b, keep_b, device):
+    """Two scaled Bernoulli keep masks (value 0 or 1/keep) from one uniform draw and one launch; a shape may be None."""
+    na = 0 if shape_a is None else int(torch.Size(shape_a).numel())
+    nb = 0 if shape_b is None else int(torch.Size(shape_b).numel())
+    u = torch.rand(na + nb, dtype=torch.float32, device=device)
+    a = torch.empty(shape_a, dtype=torch.float32, device=device) if na else None
+    b = torch.empty(shape_b, dtype=torch.float32, device=device) if nb else None
+    check(lib.nnl_keep_masks(ptr(u), ptr(a), na, float(keep_a), ptr(b), nb, float(keep_b), stream()))
+    return a, b
 
 
 def tab_embed_concat(xcat, weights, row_mask=None, cont=None, cont_mask=None, max_norm=None, plan=None, sync=None):
