@@ -573,8 +573,12 @@ def run_config(name, device, world, rank, clock, steps, warmup, cpu):
         out['eager_step'] = {'ms_per_step': round(ms, 3), 'median_ms_per_step': out['median_ms_per_step'], 'value': out['value']}
         out['hipgraph_step'] = {'ms_per_step': round(msg, 3), 'median_ms_per_step': None if medg is None else round(medg, 3),
                                 'value': round(wl.units_per_step * steps / dtg, 1)}
+        # unambiguous keys for the two modes (`ms_per_step` / `median_ms_per_step` below describe the FASTER mode only)
+        out['eager_mean_ms'], out['eager_median_ms'] = round(ms, 3), out['median_ms_per_step']
+        out['replay_mean_ms'], out['replay_median_ms'] = round(msg, 3), None if medg is None else round(medg, 3)
+        out['eager_over_replay'] = round(ms / msg, 2)
         if msg < ms:                                        # headline of this config = the product's faster mode, named
-            out.update(ms_per_step=round(msg, 3), value=out['hipgraph_step']['value'],
+            out.update(ms_per_step=round(msg, 3), value=out['hipgraph_step']['value'], median_ms_per_step=out['replay_median_ms'],
                        mode='whole-step hipGraph replay (forward + loss + backward + fused optimizer in one graph): the DEFAULT of these '
                             'launch-bound heads since round 3 (Learner enables it for models marked nnl_default_graphs); '
                             'eager_step = learner.use_graphs(False)')
