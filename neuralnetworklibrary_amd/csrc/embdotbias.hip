@@ -98,6 +98,60 @@ __global__ void embdot_g_kernel(const int64_t* __restrict__ x, const float* __re
   }
 }
 
+
+// Small minibatches (n <= 256: the MovieLens-100K notebook's 64) — the whole backward in ONE launch, no sort, no zero fill (round 4):
+// one thread per element of the contiguous gradient block [dU | dM | dbu | dbi] scans the minibatch (indices and g staged in LDS)
+// in SAMPLE ORDER and adds g * partner row on a match.  Replaces memset + g + rank sort + segment sums (4 of the 11 nodes of the
+// replayed collab step); same summation order as the sorted path for rows with few samples.
+constexpr int kScanMaxN = 256;
+
+__global__ __launch_bounds__(256) void embdot_scan_bwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ U,
+                                                              const float* __restrict__ M, const float* __restrict__ z,
+                                                              const float* __restrict__ dy, float* __restrict__ out, int n, long n_user,
+                                                              long n_item, int D, int has_range, float lo, float hi) {
+  __shared__ int su[kScanMaxN], si[kScanMaxN];
+  __shared__ float sg[kScanMaxN];
+  const int t = threadIdx.x;
+  if (t < n) {
+    const int64_t u = x[2 * t], it = x[2 * t + 1];
+    const bool ok = !((u < 0) | (u >= n_user) | (it < 0) | (it >= n_item));
+    float g = 0.f;
+    if (ok) {
+      g = dy[t];
+      if (has_range) {
+        const float sgm = 1.f / (1.f + expf(-z[t]));
+        g *= (hi - lo) * sgm * (1.f - sgm);
+      }
+    }
+    su[t] = ok ? (int)u : -1;
+    si[t] = ok ? (int)it : -1;
+    sg[t] = g;
+  }
+  __syncthreads();
+  const long nu_d = n_user * D, ni_d = n_item * D;
+  const long total = nu_d + ni_d + n_user + n_item;
+  const long f = (long)blockIdx.x * 256 + t;
+  if (f >= total) return;
+  float acc = 0.f;
+  if (f < nu_d + ni_d) {
+    const bool user = f < nu_d;
+    const long ff = user ? f : f - nu_d;
+    const int r = (int)(ff / D), d = (int)(ff - (long)r * D);
+    const int* mine = user ? su : si;
+    const int* other = user ? si : su;
+    const float* P = user ? M : U;
+    for (int s = 0; s < n; ++s)
+      if (mine[s] == r) acc += sg[s] * P[(long)other[s] * D + d];
+  } else {
+    const bool user = f < nu_d + ni_d + n_user;
+    const int r = (int)(user ? f - nu_d - ni_d : f - nu_d - ni_d - n_user);
+    const int* mine = user ? su : si;
+    for (int s = 0; s < n; ++s)
+      if (mine[s] == r) acc += sg[s];
+  }
+  out[f] = acc;
+}
+
 int grid_for(int64_t n) {
   int64_t blocks = nnl_cdiv(n, kBlock / kSub);
   if (blocks > 2048) blocks = 2048;
@@ -133,7 +187,18 @@ extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float*
   NNL_CHECK_ARG(n >= 0 && n_user > 0 && n_item > 0 && D > 0 && D < (1 << 30), "embdotbias_bwd: bad sizes");
   NNL_CHECK_ARG(dU && dM && dbu && dbi, "embdotbias_bwd: null output");
   hipStream_t s = (hipStream_t)stream;
-  if (dM == dU + n_user * D && dbu == dM + n_item * D && dbi == dbu + n_user) {
+  const bool one_block = dM == dU + n_user * D && dbu == dM + n_item * D && dbi == dbu + n_user;
+  if (one_block && n >= 1 && n <= kScanMaxN && (n_user + n_item) * (D + 1) < (1L << 31) && NNL_ENV_INT("NNL_EMBDOT_SCAN", 1) != 0 &&
+      NNL_ENV_INT("NNL_SCATTER_ATOMIC", 0) == 0) {
+    NNL_CHECK_ARG(x && U && M && dy && (z || !has_range), "embdotbias_bwd: null pointer");
+    NnlProfScope prof(NNL_PROF_EMBDOT, s, (double)n * (16 + 16.0 * D + 8 + 8));
+    const long total = (n_user + n_item) * (D + 1);
+    hipLaunchKernelGGL(embdot_scan_bwd_kernel, dim3((unsigned)nnl_cdiv(total, 256)), dim3(256), 0, s, x, U, M, z, dy, dU, (int)n, (long)n_user,
+                       (long)n_item, (int)D, has_range, lo, hi);
+    NNL_CHECK_LAUNCH();
+    return NNL_OK;
+  }
+  if (one_block) {
     // the four gradients are one allocation ([dU | dM | dbu | dbi], as ops.py hands them over): one fill instead of four
     NNL_CHECK_HIP(hipMemsetAsync(dU, 0, sizeof(float) * ((n_user + n_item) * (D + 1)), s));
   } else {

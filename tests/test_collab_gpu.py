@@ -52,7 +52,8 @@ def test_golden_three_learner_steps():
 
 
 @pytest.mark.parametrize('n,n_user,n_item,D,rng', [(64, 943, 1682, 30, True), (1, 5, 7, 1, True), (8192, 1000, 2000, 30, True),
-                                                   (333, 17, 19, 50, False), (4097, 64, 64, 128, True)])
+                                                   (333, 17, 19, 50, False), (4097, 64, 64, 128, True),
+                                                   (200, 17, 19, 50, True), (256, 3, 300, 7, False)])   # (n <= 256: the one-launch backward, rows with many samples)
 def test_vs_oracle_seeded(n, n_user, n_item, D, rng):
     from neuralnetworklibrary_amd import ops
     gen = torch.Generator().manual_seed(n + D)
