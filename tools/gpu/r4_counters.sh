@@ -4,7 +4,6 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r4p
 mkdir -p $O
-timeout -k 10 600 python bench.py > $O/bench_final.json.log 2> $O/bench_final.err; echo "bench rc=$?"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --configs none > $O/bench_under_rocprof.json.log 2>$O/rocprof_bench.err; echo "rocprof rc=$?"
 for f in $(find $O/prof_bench -name "*.db" | head -1); do python tools/stats_csv.py $f $O/bench_kernel_stats.csv; done
 timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none > /dev/null 2>$O/pmc_fetch.err; echo "pmc fetch rc=$?"
