@@ -11,7 +11,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CONV = ('igemm_', 'wino_kernel', 'wino2_kernel', 'wino2s_kernel', 'wino_filter_kernel', 'wino2_filter_kernel', 'wino2s_filter_kernel', 'wino_filter_multi_kernel', 'wino_wgrad_finish_kernel', 'slab_reduce_kernel', 'splitk_reduce_kernel', 'weight_transpose_kernel')   # everything a conv C call launches
+CONV = ('igemm_', 'wino_kernel', 'wino2_kernel', 'wino2s_kernel', 'wino_filter_kernel', 'wino2_filter_kernel', 'wino2s_filter_kernel', 'wino_filter_multi_kernel', 'wino_wgrad_finish_kernel', 'wino2d_wgrad_finish_kernel', 'slab_reduce_kernel', 'splitk_reduce_kernel', 'weight_transpose_kernel')   # everything a conv C call launches
 
 
 def load(path, name):
