@@ -844,7 +844,10 @@ def worker(args):
             # caller asks for a quick run (--steps < 10)
             quick = args.steps < 10
             k = {'collab': 200, 'tabular': 100, 'lm': 50, 'retinanet': 50}[name] if not quick else max(args.steps, 3)
-            out['configs'][name] = run_config(name, device, world, rank, clock, k, 10 if not quick else 3, cpu)
+            try:
+                out['configs'][name] = run_config(name, device, world, rank, clock, k, 10 if not quick else 3, cpu)
+            except Exception as e:                       # noqa: BLE001 — a side config must not take the headline's JSON line down
+                out['configs'][name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     if cpu:
         out['cpu_baseline'] = cpu_baseline_resnet(args.bs, args.sz)
     if rank == 0:
