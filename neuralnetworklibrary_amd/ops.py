@@ -186,7 +186,7 @@ def _pad_c4(t_nhwc):
     C = t_nhwc.shape[-1]
     if C % 4 == 0:
         return t_nhwc
-    if t_nhwc.is_cuda and t_nhwc.dtype == torch.float32 and t_nhwc.is_contiguous() and not t_nhwc.requires_grad:
+    if t_nhwc.is_cuda and t_nhwc.dtype == torch.float32 and t_nhwc.is_contiguous() and not (torch.is_grad_enabled() and t_nhwc.requires_grad):
         Cp = C + 4 - C % 4                                # one launch (torch's pad is a fill + a strided copy)
         out = torch.empty(t_nhwc.shape[:-1] + (Cp,), dtype=torch.float32, device=t_nhwc.device)
         check(lib.nnl_pad_cols(ptr(t_nhwc), ptr(out), t_nhwc.numel() // C, C, Cp, stream()))
