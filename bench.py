@@ -105,6 +105,28 @@ class Workload:
         self.loss = self.learner.train1minibatch(x, y, self.lr, **self.step_kw)
         return self.loss
 
+    def step_as_in_fit(self, i):
+        """The step as Learner.fit()'s inner loop makes it (General/Learner.py train_gen_sched): a replayed step hands back a handle,
+        and its float is read after the NEXT step has been launched; `flush()` reads the last one — every loss of the timed
+        region is read inside it."""
+        x, y = self.batches[i % len(self.batches)]
+        r = self.learner.train1minibatch(x, y, self.lr, _defer=True, **self.step_kw)
+        if self._pending is not None:
+            self.loss = self._pending.result()
+            self._pending = None
+        if hasattr(r, 'result'):
+            self._pending = r
+        else:
+            self.loss = r
+        return self.loss
+
+    _pending = None
+
+    def flush(self, _=None):
+        if self._pending is not None:
+            self.loss = self._pending.result()
+            self._pending = None
+
 
 def _learner_cls():
     from neuralnetworklibrary_amd.General.Learner import Learner
@@ -577,12 +599,35 @@ def run_config(name, device, world, rank, clock, steps, warmup, cpu):
         out['eager_mean_ms'], out['eager_median_ms'] = round(ms, 3), out['median_ms_per_step']
         out['replay_mean_ms'], out['replay_median_ms'] = round(msg, 3), None if medg is None else round(medg, 3)
         out['eager_over_replay'] = round(ms / msg, 2)
-        if msg < ms:                                        # headline of this config = the product's faster mode, named
+        # ... and as Learner.fit() drives it since round 4: the loss of a replayed step is read one step late (same values, same order),
+        # so the GPU does not idle while the host stages the next minibatch
+        wl.learner.use_graphs(True)
+        for i in range(warmup + 3):
+            wl.step_as_in_fit(i)
+        wl.flush()
+
+        def fit_steps(i):
+            wl.step_as_in_fit(i)
+            if i == steps - 1:
+                wl.flush()
+        dtf = clock.timed(fit_steps, 0, steps)
+        wl.learner.use_graphs(False)
+        msf = dtf / steps * 1e3
+        out['replay_in_fit_loop_mean_ms'] = round(msf, 3)
+        out['fit_loop_step'] = {'ms_per_step': round(msf, 3), 'value': round(wl.units_per_step * steps / dtf, 1),
+                                'note': "the replayed step inside Learner.fit()'s loop: every loss is read (inside the timed region), one step "
+                                        'after its launch; train1minibatch called on its own still returns its own float (replay_mean_ms)'}
+        if msf < msg and msf < ms:                          # headline of this config = the product's fastest mode, named
+            out.update(ms_per_step=round(msf, 3), value=out['fit_loop_step']['value'], median_ms_per_step=None,
+                       mode="whole-step hipGraph replay as Learner.fit() drives it (the default of these launch-bound heads): forward + loss + "
+                            'backward + fused optimizer in one graph, the loss read back one step late; hipgraph_step = the same replay with '
+                            'the per-step loss.item() of a bare train1minibatch call; eager_step = learner.use_graphs(False)')
+        elif msg < ms:                                      # headline of this config = the product's faster mode, named
             out.update(ms_per_step=round(msg, 3), value=out['hipgraph_step']['value'], median_ms_per_step=out['replay_median_ms'],
                        mode='whole-step hipGraph replay (forward + loss + backward + fused optimizer in one graph): the DEFAULT of these '
                             'launch-bound heads since round 3 (Learner enables it for models marked nnl_default_graphs); '
                             'eager_step = learner.use_graphs(False)')
-        ms_best = min(ms, msg)
+        ms_best = min(ms, msg, msf)
     else:
         ms_best = ms
     n_prof = 3

@@ -493,6 +493,9 @@ typedef struct {
   float decay;
 } nnl_optim_tensor_t;
 int64_t nnl_optim_chunk_elems(void);
+/* tensors[i].lr / .decay = dyn[2i] / dyn[2i+1] (i < n), hyper[0..8) = dyn[2n ..): the per-step values of a REPLAYED step, patched into the
+ * table after its captured upload (see csrc/optim.hip). */
+int nnl_optim_patch(nnl_optim_tensor_t* tensors, float* hyper, const float* dyn, int64_t n, void* stream);
 int nnl_optim_step(const nnl_optim_tensor_t* tensors, const int32_t* chunk_tensor, const int64_t* chunk_off,
                    int64_t n_chunks, int kind, const float* hyper, int use_clip, float* clip_workspace, void* stream);
 

@@ -149,13 +149,27 @@ def _tree_map(f, b):
     return f(b) if torch.is_tensor(b) else [_tree_map(f, v) for v in b]
 
 
+class _PendingLoss:
+    """The loss of a replayed step whose device->host copy is in flight (Learner.fit's inner loop reads it AFTER it has launched the
+    next step: a replayed tabular / collab step is 40-310 us and the per-step `loss.item()` of the reference, General/Learner.py:516,
+    left the GPU idle for 25-50 us while the host staged the next minibatch)."""
+    __slots__ = ('host', 'event', 'slot')
+
+    def __init__(self, host, event, slot):
+        self.host, self.event, self.slot = host, event, slot
+
+    def result(self):
+        self.event.synchronize()
+        return float(self.host[self.slot])
+
+
 class _GraphedStep:
     """One captured training step for one input signature (Learner.use_graphs)."""
 
     def __init__(self, warmup):
         self.left, self.graph, self.x, self.y, self.loss = max(int(warmup), 1), None, None, None, None
 
-    def run(self, learner, x_batch, y_batch):
+    def run(self, learner, x_batch, y_batch, defer=False):
         """Non-DP: the whole step (forward, loss, backward, fused optimizer) is one graph.  Data parallel: the graph holds forward,
         loss and backward — the gradient hooks' copies into the all-reduce buckets are captured with it — and each replay is
         followed, eagerly, by the bucket all-reduces (RCCL is not captured) and the fused optimizer launch.  The collectives then
@@ -198,12 +212,25 @@ class _GraphedStep:
                     gs.capturing, gs._active = False, False
             self.graph = graph
             self.opt_capture = None if dp else opt.captured()
+            if not dp:
+                opt.stage_captured()                     # the captured step's own lr / decay / hyper values, before its first replay
         else:
             for dst, src in zip(_tensor_leaves(self.x) + _tensor_leaves(self.y), _tensor_leaves(x_batch) + _tensor_leaves(y_batch)):
                 dst.copy_(src, non_blocking=True)
             if not dp:
                 opt.replay_step(self.opt_capture)
         self.graph.replay()
+        if defer and not dp:
+            # fit()'s pipelined loop: start the scalar's copy into one of two pinned slots and hand back a handle; the static loss
+            # tensor is overwritten by the NEXT replay, which is ordered behind this copy on the stream
+            if getattr(self, '_host', None) is None:
+                self._host = torch.empty(2, dtype=torch.float32).pin_memory()
+                self._events = [torch.cuda.Event(), torch.cuda.Event()]
+                self._slot = 0
+            self._slot ^= 1
+            self._host[self._slot:self._slot + 1].copy_(self.loss.detach().reshape(1).float(), non_blocking=True)
+            self._events[self._slot].record()
+            return _PendingLoss(self._host, self._events[self._slot], self._slot)
         if dp:
             # the replay is only ENQUEUED here: the per-bucket wait kernels + all-reduces go to a side stream now and run under the rest of
             # the replayed backward (dist.GradSync.reduce_overlapped; CPU / NNL_DIST_REPLAY_OVERLAP=0: all buckets after the replay)
@@ -555,9 +582,10 @@ class Learner(object):
             return results
 
     # ---- (5) training --------------------------------------------------------------------------------
-    def train1minibatch(self, x_batch, y_batch, lr_batch, mom_batch=None, betas_batch=None):
+    def train1minibatch(self, x_batch, y_batch, lr_batch, mom_batch=None, betas_batch=None, _defer=False):
         """One optimizer update on one minibatch; returns the minibatch loss as a float
-        (General/Learner.py:490-516)."""
+        (General/Learner.py:490-516).  _defer (fit()'s loop only): a replayed step may return a _PendingLoss handle instead, whose
+        float is read after the next step has been launched."""
         bs = _batch_size(y_batch)
         self._dp_weight = 1.0
         kd_offset = 0
@@ -582,7 +610,7 @@ class Learner(object):
         opt = self.optimizer
         opt.set_params(lr_batch, opt.wd, opt.bn_wd, opt.clip, **get_param_dict(mom_batch, betas_batch))
         if self._graph_warmup is not None:
-            loss = self._graphed_step(x_batch, y_batch)
+            loss = self._graphed_step(x_batch, y_batch, defer=_defer)
             if loss is not None:
                 return loss
         return self._eager_step(x_batch, y_batch)
@@ -634,7 +662,7 @@ class Learner(object):
         else:
             loss.backward()
 
-    def _graphed_step(self, x_batch, y_batch):
+    def _graphed_step(self, x_batch, y_batch, defer=False):
         "use_graphs(): replay (or first capture) the step for this input signature; None -> run it eagerly"
         leaves = _tensor_leaves(x_batch) + _tensor_leaves(y_batch)
         if any(t is None for t in leaves) or not self.optimizer.graph_capturable() or not self.model.training:
@@ -663,7 +691,7 @@ class Learner(object):
             if len(self._graphs) >= 4:
                 return None
             g = self._graphs[key] = _GraphedStep(self._graph_warmup)
-        return g.run(self, x_batch, y_batch)
+        return g.run(self, x_batch, y_batch, defer)
 
     @staticmethod
     def display_training_results(col_names, values, run_times):
@@ -704,6 +732,16 @@ class Learner(object):
             self.model.train()
             self._apply_bn_frozen()
 
+            # replayed steps (use_graphs): the loss of step i is read after step i + 1 has been launched, so the GPU does not idle while
+            # the host stages the next minibatch; the values, their order and everything derived from them are unchanged
+            defer = self._graph_warmup is not None and self.grad_sync is None and print_batch is False
+            pending = None
+
+            def consume(loss_value):
+                self.loss_sched.append(loss_value)
+                self.moving_avg_loss = self.moving_avg_loss * 0.98 + loss_value * 0.02
+                return self.moving_avg_loss / (1 - 0.98 ** len(self.loss_sched))
+
             for j, (x_batch, y_batch) in enumerate(self.data.train_dl):
                 tb = time.time()
                 x_batch, y_batch = to_cuda(x_batch), to_cuda(y_batch)
@@ -711,19 +749,26 @@ class Learner(object):
                 self.lr_sched.append(lr_sched[i])
                 if mom_sched:
                     self.mom_sched.append(mom_sched[i])
-                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], mom_batch=mom_sched[i])
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], mom_batch=mom_sched[i], _defer=defer)
                 elif betas_sched:
                     self.betas_sched.append(betas_sched[i])
-                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], betas_batch=betas_sched[i])
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], betas_batch=betas_sched[i], _defer=defer)
                 else:
-                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i])
-                self.loss_sched.append(loss)
-                self.moving_avg_loss = self.moving_avg_loss * 0.98 + loss * 0.02
-                debiased = self.moving_avg_loss / (1 - 0.98 ** (i + 1))
+                    loss = self.train1minibatch(x_batch, y_batch, lr_sched[i], _defer=defer)
+                if pending is not None:
+                    debiased = consume(pending.result())
+                    pending = None
+                if isinstance(loss, _PendingLoss):
+                    pending = loss
+                    continue
+                debiased = consume(loss)
 
                 if (print_batch is True) or (type(print_batch) == int and not isinstance(print_batch, bool)
                                              and (j % print_batch) == 0):
                     self._print_batch(j, debiased, loss, metrics, x_batch, y_batch, time.time() - tb)
+            if pending is not None:
+                debiased = consume(pending.result())
+                pending = None
 
             _raise_if_index_error()                       # bad ids met by this epoch's gathers (checked once, not per step)
             if self.grad_sync is not None:

@@ -93,6 +93,10 @@ class Optimizer(object):
         "handle of the step() that was just recorded under stream capture (pass it to replay_step)"
         return self._fused.last_capture
 
+    def stage_captured(self):
+        "right after a capture: upload the captured step's own per-step values before its first replay (FusedStep.stage_last)"
+        self._fused.stage_last()
+
     def replay_step(self, capture):
         "Host half of step() when the launches themselves are replayed from a captured hipGraph (Learner.use_graphs)."
         lrs, decays = self._fused_args()

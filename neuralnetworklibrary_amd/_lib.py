@@ -122,6 +122,7 @@ SIGNATURES = {
     'nnl_seq_reg_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, C.c_float, C.c_float, c_p]),
     'nnl_weight_drop': (C.c_int, [c_p, i64, c_p, c_p, i64, i64, i64, C.c_uint64, C.c_float, c_p]),
     'nnl_optim_chunk_elems': (i64, []),
+    'nnl_optim_patch': (C.c_int, [c_p, c_p, c_p, i64, c_p]),
     'nnl_optim_step': (C.c_int, [c_p, c_p, c_p, i64, C.c_int, c_p, C.c_int, c_p, c_p]),
     'nnl_bn_workspace_bytes': (sz, [i64, i64]),
     'nnl_bn_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, f32, f32, C.c_int, C.c_int, c_p, c_p, c_p, i64,

@@ -96,6 +96,24 @@ __global__ __launch_bounds__(kBlock) void optim_step_kernel(const nnl_optim_tens
 
 }  // namespace
 
+// Replayed steps (Learner.use_graphs): the captured upload node re-reads ONE pinned image of the table, which the host may therefore not
+// rewrite while an earlier replay is still in flight.  The values that change from step to step (per-tensor lr / decay, the 8
+// hyper-parameter floats) travel separately — an eager, stream-ordered upload from a ring of pinned buffers into `dyn` before each
+// replay — and this captured kernel patches them into the table after the static image has landed, so fit()'s loop can run ahead
+// of the GPU (round 4).  dyn = [n x {lr, decay}] then 8 floats.
+__global__ void optim_patch_kernel(nnl_optim_tensor_t* __restrict__ tensors, float* __restrict__ hyper, const float* __restrict__ dyn, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { tensors[i].lr = dyn[2 * i]; tensors[i].decay = dyn[2 * i + 1]; }
+  if (i < 8) hyper[i] = dyn[2 * n + i];
+}
+
+extern "C" int nnl_optim_patch(nnl_optim_tensor_t* tensors, float* hyper, const float* dyn, int64_t n, void* stream) {
+  NNL_CHECK_ARG(tensors && hyper && dyn && n > 0 && n < (1 << 24), "optim_patch: bad arguments");
+  hipLaunchKernelGGL(optim_patch_kernel, dim3((unsigned)nnl_cdiv(n > 8 ? n : 8, 256)), dim3(256), 0, (hipStream_t)stream, tensors, hyper, dyn, (int)n);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
+}
+
 extern "C" int64_t nnl_optim_chunk_elems(void) { return kChunk; }
 
 extern "C" int nnl_optim_step(const nnl_optim_tensor_t* tensors, const int32_t* chunk_tensor, const int64_t* chunk_off,

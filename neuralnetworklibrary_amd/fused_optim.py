@@ -56,6 +56,11 @@ class FusedStep:
         self.table_bytes = n * _DESC.itemsize
         self.host = [torch.empty(self.table_bytes + 32, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.dev = torch.empty(self.table_bytes + 32, dtype=torch.uint8, device=self.device)
+        # replayed steps: the per-step values (lr, decay per tensor + 8 hyper floats) reach the device through `dyn`, uploaded eagerly
+        # from a ring of pinned buffers before each replay and patched into the table by a captured kernel (nnl_optim_patch)
+        self.dyn = torch.zeros(2 * n + 8, dtype=torch.float32, device=self.device)
+        self._ring, self._ring_ev, self._ring_k = None, None, 0
+        self._capture_dyn = None
         self.clip_ws = torch.empty(self.n_chunks + 2, dtype=torch.float32, device=self.device)
         self.flip = 0
         self.steps = 0
@@ -145,9 +150,16 @@ class FusedStep:
             self.flip ^= 1
         hn = h.numpy()
         hn[:self.table_bytes] = desc.view(np.uint8)
-        hn[self.table_bytes:].view(np.float32)[:] = self._advance_hyper(clip)
+        hyper_vec = self._advance_hyper(clip)
+        hn[self.table_bytes:].view(np.float32)[:] = hyper_vec
         self.dev.copy_(h, non_blocking=True)
         hyper = self.dev.data_ptr() + self.table_bytes
+        if capturing:
+            # the captured upload re-reads the pinned image at every replay: the host never rewrites it again; what changes per step
+            # comes through `dyn` (stage_last() / replay_update(), eager) and is patched in by this captured kernel
+            g = np.asarray(self.group_of)
+            self._capture_dyn = (np.asarray(lrs, dtype=np.float32)[g], np.asarray(decays, dtype=np.float32)[g], hyper_vec)
+            check(lib.nnl_optim_patch(ptr(self.dev), hyper, ptr(self.dyn), len(self.params), stream()))
         check(lib.nnl_optim_step(ptr(self.dev), ptr(self.chunk_tensor), ptr(self.chunk_off), self.n_chunks, self.kind,
                                  hyper, 1 if clip else 0, ptr(self.clip_ws), stream()))
 
@@ -156,13 +168,34 @@ class FusedStep:
         self._init_state()
         self._capture_buf = torch.empty(self.table_bytes + 32, dtype=torch.uint8).pin_memory()
 
+    def _stage_dyn(self, lr_t, decay_t, hyper_vec):
+        "eager, stream-ordered upload of one step's values into `dyn` from the next pinned ring slot (8 slots: a slot is reused only after its copy has completed)"
+        n = len(self.params)
+        if self._ring is None:
+            self._ring = [torch.empty(2 * n + 8, dtype=torch.float32).pin_memory() for _ in range(8)]
+            self._ring_ev = [None] * 8
+        k = self._ring_k
+        self._ring_k = (k + 1) % 8
+        if self._ring_ev[k] is not None:
+            self._ring_ev[k].synchronize()
+        else:
+            self._ring_ev[k] = torch.cuda.Event()
+        r = self._ring[k].numpy()
+        r[0:2 * n:2] = lr_t
+        r[1:2 * n:2] = decay_t
+        r[2 * n:] = hyper_vec
+        self.dyn.copy_(self._ring[k], non_blocking=True)
+        self._ring_ev[k].record()
+
+    def stage_last(self):
+        "right after a capture, before its first replay: the values the captured step() was called with"
+        if self._capture_dyn is not None:
+            self._stage_dyn(*self._capture_dyn)
+            self._capture_dyn = None
+
     def replay_update(self, capture, lrs, decays, clip):
-        """Before replaying a captured training step (`capture` = last_capture taken right after it was recorded): refresh
-        the per-tensor lr / decay and the hyper-parameter vector in the staging buffer the captured copy node reads
-        (pointers are unchanged: the graph owns the gradient memory)."""
-        hn = capture[0].numpy()
-        d = hn[:self.table_bytes].view(_DESC)
+        """Before replaying a captured training step: this step's per-tensor lr / decay and hyper-parameter vector go to `dyn`
+        (the captured nnl_optim_patch writes them into the table); the pinned image the captured upload re-reads is never touched
+        again, so the host may stage step i + 1 while step i is still running (Learner.fit's deferred loss read-back)."""
         g = np.asarray(self.group_of)
-        d['lr'] = np.asarray(lrs, dtype=np.float32)[g]
-        d['decay'] = np.asarray(decays, dtype=np.float32)[g]
-        hn[self.table_bytes:].view(np.float32)[:] = self._advance_hyper(clip)
+        self._stage_dyn(np.asarray(lrs, dtype=np.float32)[g], np.asarray(decays, dtype=np.float32)[g], self._advance_hyper(clip))

@@ -249,3 +249,45 @@ def test_launch_bound_heads_replay_by_default(monkeypatch):
     monkeypatch.delenv('NNL_DEFAULT_GRAPHS')
     plain = make_model_basic(nn.Sequential(nn.Linear(4, 1), nn.Flatten(0)))
     assert Learner('/tmp/nnl_graph_test', Data([batch], 64, 'cont'), plain)._graph_warmup is None
+
+
+def test_fit_reads_replayed_losses_one_step_late_and_records_the_same_schedule():
+    """Learner.fit()'s inner loop launches step i + 1 before it reads the loss of the replayed step i (round 4: the per-step
+    `loss.item()` left the GPU idle while the host staged the next minibatch).  The recorded loss schedule, the moving average
+    and the trained parameters must equal those of the same steps made one by one with train1minibatch (which still returns
+    the float of its own step); ragged last minibatch (eager, then its own graph) and two epochs included."""
+    from neuralnetworklibrary_amd.Applications.CollabFiltering import CollabFilterNet
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    g = torch.Generator().manual_seed(31)
+    def batch(n):
+        return (torch.stack([torch.randint(0, 50, (n,), generator=g), torch.randint(0, 70, (n,), generator=g)], 1).to(DEV),
+                torch.randint(1, 6, (n,), generator=g).float().to(DEV))
+    batches = [batch(64) for _ in range(7)] + [batch(23)]
+    runs = []
+    for mode in ('fit', 'steps'):
+        torch.manual_seed(0)
+        net = CollabFilterNet(50, 70, 12, [0.8, 5.2])
+        learner = Learner('/tmp/nnl_graph_fit', Data(batches, 64, 'cont'), net, optimizer='Adam')
+        learner.use_graphs(True, warmup=2)
+        if mode == 'fit':
+            learner.fit(1e-2, 2, wd=1e-3)
+            losses, avg = list(learner.loss_sched), learner.moving_avg_loss
+        else:
+            learner.init_optimizer(wd=1e-3)
+            learner.model.train()
+            losses, avg = [], 0.0
+            for ep in range(2):
+                for x, y in batches:
+                    losses.append(learner.train1minibatch(x, y, 1e-2))
+                    avg = avg * 0.98 + losses[-1] * 0.02
+        assert sum(gr.graph is not None for gr in learner._graphs.values()) >= 1
+        runs.append((losses, avg, [p.detach().cpu().numpy().copy() for p in net.parameters()]))
+    (lf, af, pf), (ls, as_, ps) = runs
+    assert len(lf) == len(ls) == 16
+    assert_close(np.array(lf), np.array(ls), 1e-6, 1e-7, 'loss schedule')
+    assert abs(af - as_) <= 1e-6 * max(abs(as_), 1e-12)
+    for a, b in zip(pf, ps):
+        assert_close(a, b, 1e-6, 1e-8, 'params')

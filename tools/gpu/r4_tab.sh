@@ -1,5 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4tab
-timeout -k 10 900 python -m pytest tests/test_tabular.py tests/test_conv_gpu.py tests/test_vision_gpu.py tests/test_e2e_gpu.py -x -q -m gpu -k "not winograd and not wgrad_wino and not g13" > gpurun_out/r4tab/test.log 2>&1; rc=$?; tail -3 gpurun_out/r4tab/test.log; echo test_rc=$rc
+timeout -k 10 900 python -m pytest tests/test_graph_gpu.py tests/test_e2e_gpu.py tests/test_step_loss_parity.py tests/test_fcnet_fit_curves.py tests/test_host_logic.py -x -q -m gpu > gpurun_out/r4tab/test.log 2>&1; rc=$?; tail -3 gpurun_out/r4tab/test.log; echo test_rc=$rc
 [ $rc -eq 0 ] || exit $rc
-for k in 1 2 3; do timeout -k 10 200 python tools/bench_heads.py tabular --steps 300 --graphs 2>/dev/null | tail -1 | cut -c1-140; done
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --configs collab,tabular 2>gpurun_out/r4tab/bench.err | tail -1 > gpurun_out/r4tab/bench_heads.json
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r4tab/bench_heads.json').read())
+for k,c in d['configs'].items():
+    print(k, c.get('ms_per_step'), c.get('value'), {x:c.get(x) for x in ('eager_mean_ms','replay_mean_ms','replay_in_fit_loop_mean_ms')}, (c.get('mode') or '')[:60], c.get('error'))
+PY
