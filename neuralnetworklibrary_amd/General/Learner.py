@@ -225,11 +225,14 @@ class _GraphedStep:
             # tensor is overwritten by the NEXT replay, which is ordered behind this copy on the stream
             if getattr(self, '_host', None) is None:
                 self._host = torch.empty(2, dtype=torch.float32).pin_memory()
+                self._host_views = [self._host[0:1], self._host[1:2]]
                 self._events = [torch.cuda.Event(), torch.cuda.Event()]
+                self._loss_src = self.loss.detach().reshape(1) if self.loss.dtype == torch.float32 else None     # a VIEW of the graph's static loss tensor
                 self._slot = 0
+                self._stream = torch.cuda.current_stream()                     # (Event.record() without a stream costs 10 us of Python)
             self._slot ^= 1
-            self._host[self._slot:self._slot + 1].copy_(self.loss.detach().reshape(1).float(), non_blocking=True)
-            self._events[self._slot].record()
+            self._host_views[self._slot].copy_(self._loss_src if self._loss_src is not None else self.loss.detach().reshape(1).float(), non_blocking=True)
+            self._events[self._slot].record(self._stream)
             return _PendingLoss(self._host, self._events[self._slot], self._slot)
         if dp:
             # the replay is only ENQUEUED here: the per-bucket wait kernels + all-reduces go to a side stream now and run under the rest of

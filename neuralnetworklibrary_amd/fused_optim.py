@@ -95,14 +95,21 @@ class FusedStep:
         self.steps += 1
         if self.kind == 0:
             return [float(g0['momentum']), 0., 0., 0., 1., 1.]
-        st0 = self.opt.state[self.params[0]]
-        step = int(st0['step'].item()) + 1
-        seen = set()
-        for p in self.params:                               # fresh states share ONE counter tensor; loaded ones may not
-            t = self.opt.state[p]['step']
-            if id(t) not in seen:
-                seen.add(id(t))
-                t += 1
+        # fresh states share ONE counter tensor; loaded ones may not.  The list of distinct counters is cached against the identity of
+        # the first one (a load_state_dict replaces the tensors): walking every parameter's state cost 8 us per replayed step
+        st0 = self.opt.state[self.params[0]]['step']
+        cache = getattr(self, '_step_cache', None)
+        if cache is None or cache[0] is not st0:
+            seen, uniq = set(), []
+            for p in self.params:
+                t = self.opt.state[p]['step']
+                if id(t) not in seen:
+                    seen.add(id(t))
+                    uniq.append(t)
+            cache = self._step_cache = (st0, uniq)
+        step = int(st0) + 1
+        for t in cache[1]:
+            t += 1
         b1, b2 = (float(b) for b in g0['betas'])
         return [0., b1, b2, float(g0['eps']), 1.0 - b1 ** step, float(np.sqrt(1.0 - b2 ** step))]
 
@@ -185,11 +192,19 @@ class FusedStep:
         r[1:2 * n:2] = decay_t
         r[2 * n:] = hyper_vec
         self.dyn.copy_(self._ring[k], non_blocking=True)
-        self._ring_ev[k].record()
+        self._ring_ev[k].record(self._stream())             # (Event.record() without a stream looks the current one up: 10 us of Python)
+
+    def _stream(self):
+        "torch's current stream, looked up once per thread-visible change of it (the replay path always runs on one stream)"
+        s = getattr(self, '_cur_stream', None)
+        if s is None:
+            s = self._cur_stream = torch.cuda.current_stream()
+        return s
 
     def stage_last(self):
         "right after a capture, before its first replay: the values the captured step() was called with"
         if self._capture_dyn is not None:
+            self._cur_stream = torch.cuda.current_stream()  # the stream the graph is replayed on
             self._stage_dyn(*self._capture_dyn)
             self._capture_dyn = None
 
