@@ -306,6 +306,10 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
   int best = 0;
   if (forced >= 0 && forced < 4) {
     best = forced;
+  } else if (p.ntaps == 1 && p.C <= 512 && p.Nc >= 8192 && p.M >= 1024 && p.ncls <= 1) {
+    // a Linear onto a huge vocabulary (the AWD-LSTM decoder, Text.py:572: 4480 x 400 -> 47 343): 25 k steps per tile, so the launch is
+    // prologue / epilogue / B-re-read bound and the 128 x 128 tile wins (measured, tools/bench_decoder_gemm.py: 1.81 -> 1.49 ms)
+    best = 0;
   } else {
     double best_t = 1e300;
     for (int i = 0; i < 4; ++i) {
