@@ -291,3 +291,44 @@ def test_fit_reads_replayed_losses_one_step_late_and_records_the_same_schedule()
     assert abs(af - as_) <= 1e-6 * max(abs(as_), 1e-12)
     for a, b in zip(pf, ps):
         assert_close(a, b, 1e-6, 1e-8, 'params')
+
+
+def test_fit_loop_runs_ahead_of_the_gpu_with_per_step_schedules():
+    """The pipelined fit loop stages step i + 1 (inputs, lr / betas / Adam bias corrections) while step i may still be running:
+    the replayed optimizer must read EACH step's own values (they travel through a ring of pinned buffers into a device buffer that a
+    captured kernel patches into the descriptor table — a single pinned image was overwritten one step early, which the G10
+    tabular curve caught).  64 steps with a different lr and betas on every step against the same steps made one by one."""
+    from neuralnetworklibrary_amd.Applications.StructuredData import StructuredDataNet
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    cards = [11, 5, 7]
+    rs = np.random.RandomState(9)
+    def batch(n):
+        xcat = torch.from_numpy(np.stack([rs.randint(0, c, size=n) for c in cards], 1).astype(np.int64)).to(DEV)
+        xcont = torch.from_numpy(rs.standard_normal((n, 2)).astype(np.float32)).to(DEV)
+        return [xcat, xcont], torch.from_numpy((5 + 7 * rs.rand(n)).astype(np.float32)).to(DEV)
+    batches = [batch(32) for _ in range(8)]
+    n_steps = 64
+    lr_sched = [[1e-3 * (1 + 0.2 * (i % 7)), 3e-3 * (1 + 0.1 * (i % 5))] for i in range(n_steps)]
+    betas_sched = [(0.9 - 0.005 * (i % 11), 0.99 - 0.001 * (i % 3)) for i in range(n_steps)]
+    runs = []
+    for mode in ('fit', 'steps'):
+        torch.manual_seed(1)
+        net = StructuredDataNet('cont', 3, 2, [{i: i for i in range(c)} for c in cards], [24, 12, 1], output_range=[5, 12])
+        learner = Learner('/tmp/nnl_graph_fit2', Data(batches, 32, 'cont'), net, optimizer='Adam')
+        learner.init_optimizer(wd=1e-3)
+        learner.use_graphs(True, warmup=2)
+        if mode == 'fit':
+            learner.train_gen_sched(lr_sched, None, betas_sched)
+            losses = list(learner.loss_sched)
+        else:
+            learner.model.train()
+            losses = [learner.train1minibatch(*batches[i % 8], lr_sched[i], betas_batch=betas_sched[i]) for i in range(n_steps)]
+        runs.append((losses, [p.detach().cpu().numpy().copy() for p in net.parameters()]))
+    (lf, pf), (ls, ps) = runs
+    assert len(lf) == n_steps
+    assert_close(np.array(lf), np.array(ls), 1e-6, 1e-7, 'loss schedule')
+    for a, b in zip(pf, ps):
+        assert_close(a, b, 1e-6, 1e-8, 'params')
