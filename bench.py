@@ -837,7 +837,7 @@ def worker(args):
                 if graphs and gs2 is not None:
                     if gs2.overlap is not None:
                         gs2.raise_if_overlap_error()
-                        strong[tag]['buckets_signalled_in_the_captured_backward'] = '%d of %d' % (gs2.overlap.signalled, len(gs2.buckets))
+                        strong[tag]['buckets_signalled_in_the_captured_backward'] = '%d of %d' % (gs2.last_signalled or 0, len(gs2.buckets))
                         strong[tag]['collectives_behind_wait_kernels'] = gs2.overlap_launches
                     if tag == 'local_bn_hipgraph':           # stand-alone all-reduce time of this step's buckets: the yardstick of the overlap
                         def ar_only(_):
@@ -846,9 +846,19 @@ def worker(args):
                                 hh.wait()
                         strong['allreduce_ms_standalone'] = round(clock.timed(ar_only, 2, 5) / 5 * 1e3, 3)
                 del w2
+                ok = 1.0
             except Exception as e:                       # noqa: BLE001 — reported, not raised: the headline above is already measured
                 strong[tag] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+                ok = 0.0
             torch.cuda.empty_cache()
+            if world > 1:
+                # the ranks agree on the leg's outcome before the next one starts: a failure that every rank meets at the same
+                # point (an overlap time-out, a deterministic Python error) leaves all of them here together; rank 0's report then says so
+                # even when its own copy of the leg went through
+                okt = torch.tensor([ok], device=device)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                if float(okt.item()) < 1.0 and 'error' not in strong[tag]:
+                    strong[tag] = {'error': 'the leg failed on another rank', 'this_rank': strong[tag]}
         os.environ.pop('NNL_DIST_REPLAY_OVERLAP', None)
         have = all('ms_per_step' in strong.get(k, {}) for k in ('local_bn_hipgraph_no_overlap', 'local_bn_hipgraph'))
         saved = strong['local_bn_hipgraph_no_overlap']['ms_per_step'] - strong['local_bn_hipgraph']['ms_per_step'] if have else 0.0

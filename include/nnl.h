@@ -59,10 +59,11 @@ int nnl_prof_collect2(int64_t* launches, double* total_ms, double* total_work, d
  * single-GPU reference — SURVEY.md 8e).  A captured training step contains nnl_dp_bump(step) at its start and nnl_dp_signal(flag + k, step)
  * right after the last gradient of all-reduce bucket k; after each replay the host enqueues, on a side stream, nnl_dp_wait(flag + k, n, ...)
  * (n = number of replays so far) followed by bucket k's RCCL all-reduce, which therefore starts while the rest of the replayed backward
- * still runs.  The wait kernel is one lane polling with s_sleep, bounded by max_polls (then *err = 1 and it returns: the stream always drains). */
+ * still runs.  The wait kernel is one lane polling with s_sleep, bounded in WALL TIME by timeout_us (the device's constant-rate counter; then
+ * *err = 1 and it returns: the stream always drains; the host reads *err with the step's loss and raises). */
 int nnl_dp_bump(int32_t* step, void* stream);
 int nnl_dp_signal(int32_t* flag, const int32_t* step, void* stream);
-int nnl_dp_wait(const int32_t* flag, int32_t value, int64_t max_polls, int32_t* err, void* stream);
+int nnl_dp_wait(const int32_t* flag, int32_t value, int64_t timeout_us, int32_t* err, void* stream);
 /* First 16 hex digits of the sha256 over the library's sources (csrc/ *.hip, *.h, Makefile, include/nnl.h; csrc/Makefile) it was built from. */
 const char* nnl_source_stamp(void);
 

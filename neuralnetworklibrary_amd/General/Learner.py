@@ -208,7 +208,7 @@ class _GraphedStep:
                         opt.step()
             finally:
                 if dp:
-                    gs.capture_end()
+                    self.signalled = gs.capture_end()    # buckets signalled inside THIS graph (None: no overlap protocol captured)
                     gs.capturing, gs._active = False, False
             self.graph = graph
             self.opt_capture = None if dp else opt.captured()
@@ -237,8 +237,11 @@ class _GraphedStep:
         if dp:
             # the replay is only ENQUEUED here: the per-bucket wait kernels + all-reduces go to a side stream now and run under the rest of
             # the replayed backward (dist.GradSync.reduce_overlapped; CPU / NNL_DIST_REPLAY_OVERLAP=0: all buckets after the replay)
-            gs.reduce_overlapped(learner._dp_weight)
+            gs.reduce_overlapped(learner._dp_weight, getattr(self, 'signalled', None))
             opt.step()
+            loss = self.loss.item()                      # (the step's one host sync; the overlap error word's copy was enqueued before it)
+            gs.raise_if_overlap_error(synced=True)
+            return loss
         return self.loss.item()
 
 

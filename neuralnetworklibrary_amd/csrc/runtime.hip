@@ -102,8 +102,9 @@ extern "C" int nnl_prof_collect2(int64_t* launches, double* total_ms, double* to
 // torch forbids external events on ROCm, so a replayed graph cannot record an event another stream waits for.  Instead the captured
 // backward contains, right after the last gradient of bucket k has been written, a one-lane SIGNAL kernel that publishes the replay
 // counter (a device word the graph itself bumps at its start) into flag[k]; after the replay has been enqueued, the host launches on
-// a side stream a one-lane WAIT kernel per bucket that polls flag[k] (relaxed system-scope loads, s_sleep between polls, BOUNDED:
-// on time-out it raises *err and returns, so the stream always drains) followed, in stream order, by the bucket's all-reduce.  The
+// a side stream a one-lane WAIT kernel per bucket that polls flag[k] (relaxed system-scope loads, s_sleep between polls, BOUNDED in
+// WALL TIME — the constant-rate counter `wall_clock64()`, not a poll count, so a slow or pre-empted replay cannot trip it: on time-out
+// it raises *err and returns, so the stream always drains) followed, in stream order, by the bucket's all-reduce.  The
 // gradient bytes are visible to the collective by ordinary kernel-boundary semantics: they were written by kernels that completed
 // before the signal kernel started, and the collective's kernels start after the wait kernel ended.
 namespace {
@@ -111,15 +112,19 @@ __global__ void dp_bump_kernel(int* step) { *step = *step + 1; }
 __global__ void dp_signal_kernel(int* flag, const int* step) {
   __hip_atomic_store(flag, *step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void dp_wait_kernel(const int* flag, int value, long max_polls, int* err) {
-  for (long i = 0; i < max_polls; ++i) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value >= 0) {      // (wrap-safe comparison)
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return;
+__global__ void dp_wait_kernel(const int* flag, int value, long long timeout_ticks, int* err) {
+  const long long t0 = (long long)wall_clock64();
+  for (;;) {
+    for (int i = 0; i < 64; ++i) {
+      if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - value >= 0) {    // (wrap-safe comparison)
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(32);
     }
-    __builtin_amdgcn_s_sleep(32);
+    if ((long long)wall_clock64() - t0 > timeout_ticks) break;
   }
-  *err = 1;
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 
@@ -135,9 +140,16 @@ extern "C" int nnl_dp_signal(int32_t* flag, const int32_t* step, void* stream) {
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }
-extern "C" int nnl_dp_wait(const int32_t* flag, int32_t value, int64_t max_polls, int32_t* err, void* stream) {
-  NNL_CHECK_ARG(flag && err && max_polls > 0, "dp_wait: bad argument");
-  hipLaunchKernelGGL(dp_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value, (long)max_polls, err);
+extern "C" int nnl_dp_wait(const int32_t* flag, int32_t value, int64_t timeout_us, int32_t* err, void* stream) {
+  NNL_CHECK_ARG(flag && err && timeout_us > 0, "dp_wait: bad argument");
+  static thread_local int rate_khz = 0;                   // wall_clock64() ticks per millisecond (100 000 on gfx950)
+  if (rate_khz <= 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0)
+      rate_khz = 100000;
+  }
+  const long long ticks = (long long)((double)timeout_us * 1e-3 * (double)rate_khz);
+  hipLaunchKernelGGL(dp_wait_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value, ticks, err);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

@@ -12,6 +12,13 @@
 // Replaces cuDNN's Winograd convolutions in the reference's 3x3 layers (retinanet.py:43-59,77-97,126-148,187-217,260-295), where the
 // dispatcher (conv2d.hip: wino_mode) predicts it >= 10 % under the 1-D kernel.  Schedule: the balanced plan of the other conv kernels
 // with its own fitted cost model (w2_cost below).  Measured: profiles/README.md, r3_wino2d_*.
+//
+// SMALL GRIDS (round 5; the strong-scaling regime, 8 - 32 images per GPU): a 14^2 / 7^2 stage at 8 images is 28 / 16 tiles for 256 CUs, and
+// the k-sliced plan above makes every slice carry FOUR output-pixel slabs and the last arriver of a tile read them all back (1 MB for 16
+// slices).  The POSITION-SPLIT instantiation (POS = true) gives every workgroup ONE position (xi, nu) of one tile — or a channel slice
+// of one — so its accumulator IS M_{xi nu}: no fold, no y tiles (16 accumulator registers instead of 80), one slab per slice; the tile's
+// last arriver sums the channel slices of each position and applies A^T M A (coefficients 0 / +-1) from the 16 M tiles.  The natural
+// 16-way (x channel slices) split fills the chip where the direct kernel runs one or two workgroups per CU at ~47 TF/s.
 #include "wino.h"
 #include "wino_filter.h"
 #include "igemm_taps.h"
@@ -43,6 +50,7 @@ struct Wino2Params {
   float* tail_out; long tail_slab_stride;
   int* tile_counters;
   float* bn_part; const float* bn_pivot;
+  int pos_cs;          // POS instantiation: channel slices per position (slices per tile = 16 * pos_cs; C / BK divisible by pos_cs)
 };
 
 __global__ void wino2_filter_kernel(const float* __restrict__ w, float* __restrict__ u, long KC, int C, int flip) {
@@ -52,7 +60,7 @@ __global__ void wino2_filter_kernel(const float* __restrict__ w, float* __restri
   wino2_filter_item(w + k * 9 * C + c, u + k * 16 * C + c, C, flip);
 }
 
-template <int BK, int OCC>
+template <int BK, int OCC, bool POS = false>
 __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
   constexpr int BM = 64, BN = 64, BKP = BK + 4, KC = BK / 4, RPP = 256 / KC, PA = BM / RPP, PB = BN / RPP;
   __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BKP];
@@ -174,7 +182,11 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
 
   f32x16 y00, y01, y10, y11, tm;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { y00[e] = 0.f; y01[e] = 0.f; y10[e] = 0.f; y11[e] = 0.f; tm[e] = 0.f; }
+  for (int e = 0; e < 16; ++e) { tm[e] = 0.f; }
+  if constexpr (!POS) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { y00[e] = 0.f; y01[e] = 0.f; y10[e] = 0.f; y11[e] = 0.f; }
+  }
   // k order: channel CHUNK (p.ch channels) outermost, the 16 positions, the chunk's BK blocks innermost.  Default chunk = all of C
   // (position-major: one fold per position).  Smaller chunks bring the four uses of a patch pixel closer together (the position-
   // major order streams the input 16 times from beyond the L2: profiles/r3_traffic.json) at the price of a fold every chunk —
@@ -221,6 +233,7 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+    if constexpr (POS) continue;                       // one position per workgroup: tm IS the slice's share of M_t
     if (++cs_cur == cpc || kt + 1 == kend) {          // the position's blocks of this chunk (or this slice of them) are done: fold tm in
       const int xi = t_cur >> 2, nu = t_cur & 3;
       const float cp0 = xi < 3 ? 1.f : 0.f, cp1 = xi == 0 ? 0.f : (xi == 2 ? -1.f : 1.f);
@@ -252,6 +265,96 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
   // ---- epilogue: quad row -> pixels (2i + p, 2j + q) ----
   const int col_l = lane & 31, row_h = (lane >> 5) * 4;
   constexpr int kSc1 = 1 << 4;
+  if constexpr (POS) {
+    // slab [slice = t * cs + s][quad row][Nc] of M_t partial sums (sc1 stores), drain, ticket; the tile's last slice sums the channel
+    // slices of every position in slice order and applies the output transform — bitwise reproducible whoever is last
+    __shared__ int ticket;
+    const long sstride = p.main_slab_stride;                 // M4 * Nc
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.main_out, 0, (int)((long)nslices * sstride * 4), 0x00020000);
+    const int cl = n0 + wn * 32 + col_l;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + row_h;
+      const long off = (long)kslice * sstride + (long)row * p.Nc + cl;
+      const bool ok = row < p.M4 && cl < p.Nc;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tm[e]), rs, ok ? (int)(off * 4) : -1, 0, kSc1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ticket = __hip_atomic_fetch_add(&p.tile_counters[logical], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != nslices - 1) return;
+    if (tid == 0) __hip_atomic_store(&p.tile_counters[logical], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest
+    float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int c4 = n0 + (tid & 15) * 4, cs = p.pos_cs;
+    const int wrow = p.W * p.Nc;
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const int row = m0 + (tid >> 4) + 16 * k4;
+      if (row >= p.M4 || c4 >= p.Nc) continue;
+      const unsigned o0 = (unsigned)(((long)row * p.Nc + c4) * 4);
+      f32x4 m[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) m[t] = buf_load4_pol(rs, o0 + (unsigned)((long)(t * cs) * sstride * 4), kSc1);     // 16 loads in flight
+      for (int sl = 1; sl < cs; ++sl) {
+#pragma unroll
+        for (int t0 = 0; t0 < 16; t0 += 8) {                   // (eight at a time: 16 more float4 would spill at four workgroups per CU)
+          f32x4 part[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) part[t] = buf_load4_pol(rs, o0 + (unsigned)((long)((t0 + t) * cs + sl) * sstride * 4), kSc1);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) m[t0 + t] += part[t];
+        }
+      }
+      // A^T M A: rows first (r0 = m0 + m1 + m2, r1 = m1 - m2 + m3 over nu), then the same pattern over xi
+      f32x4 r0[4], r1[4];
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        r0[xi] = (m[xi * 4 + 0] + m[xi * 4 + 1]) + m[xi * 4 + 2];
+        r1[xi] = (m[xi * 4 + 1] - m[xi * 4 + 2]) + m[xi * 4 + 3];
+      }
+      f32x4 out[4];
+      out[0] = (r0[0] + r0[1]) + r0[2];                        // (p, q) = (0, 0)
+      out[1] = (r1[0] + r1[1]) + r1[2];                        // (0, 1)
+      out[2] = (r0[1] - r0[2]) + r0[3];                        // (1, 0)
+      out[3] = (r1[1] - r1[2]) + r1[3];                        // (1, 1)
+      const int l2 = qdiv(row, p.mg_W2), j = row - l2 * p.W2;
+      const int n = qdiv(l2, p.mg_H2), ii = l2 - n * p.H2;
+      const long ob = (((long)n * p.H + 2 * ii) * p.W + 2 * j) * p.Nc + c4;
+      const bool h1 = 2 * ii + 1 < p.H, w1 = 2 * j + 1 < p.W;
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        if (((h >> 1) && !h1) || ((h & 1) && !w1)) continue;  // the missing outputs of an odd height / width
+        f32x4 v = out[h];
+        const long o = ob + (h >> 1) * wrow + (h & 1) * p.Nc;
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + c4);
+        if (p.add) v += *reinterpret_cast<const f32x4*>(p.add + o);
+        if (p.relu == 1) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        *reinterpret_cast<f32x4*>(p.y + o) = v;
+        if (p.bn_part) {
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(p.bn_pivot + c4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; fs1[e] += d; fs2[e] += d * d; }
+        }
+      }
+    }
+    if (p.bn_part) {
+      __syncthreads();
+      float* red = &lds[0][0];                       // [16 row lanes][64 cols][2]
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 0] = fs1[e];
+        red[(((tid >> 4) * 64) + (tid & 15) * 4 + e) * 2 + 1] = fs2[e];
+      }
+      __syncthreads();
+      if (tid < 64 && n0 + tid < p.Nc) {
+        float a = 0.f, b = 0.f;
+        for (int r = 0; r < 16; ++r) { a += red[(r * 64 + tid) * 2]; b += red[(r * 64 + tid) * 2 + 1]; }
+        p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 0] = a;
+        p.bn_part[((long)tile_m * p.Nc + n0 + tid) * 2 + 1] = b;
+      }
+    }
+    return;
+  }
   if (partial) {
     // split tile: sc1 stores of the partial quad sums, drain, ticket; the last slice sums the slabs in slice order and finishes
     __shared__ int ticket;
@@ -390,7 +493,22 @@ struct W2Plan {
   int bk, on, main_ks, n_main_tiles, tail_slices, tail_row0;
   size_t main_floats, tail_floats;
   double t_us;
+  int pos_cs;          // > 0: the position-split instantiation with that many channel slices per position (main_floats = its M slabs)
 };
+
+// Cost of the position-split schedule (us): T tiles x 16 positions x cs channel slices, every workgroup runs C / 32 / cs iterations of the
+// BK 32 loop with one accumulator; a CU's nb workgroups, c of them co-resident, cost nb * I * (b + a / c) like the plan above (same loop,
+// same fitted a / b); per workgroup generation a prologue + one-tile slab store, then per tile the last arriver's serial tail: 16 * cs slab
+// tiles read back (4 dependent rounds of 16 loads per slice count) + the four-pixel epilogue.  Constants set from forced-mode sweeps at
+// 8 / 16 / 32 images (tools/bench_conv.py --ab NNL_WINO2_POS=0,1..., profiles/r5_wino2_pos_*.log).
+double w2_pos_cost(long T, long M4, int Nc, int C, int cs) {
+  const double a = 0.363, b = 0.490, tfix = 4.0;
+  const long occ = 4, nwg = T * 16 * cs, I = (C / 32) / cs;
+  const long nb = nnl_cdiv(nwg, (long)kCUs);
+  const double c = (double)(nb < occ ? nb : occ);
+  const double slab_b = 2.0 * 16 * cs * (double)M4 * Nc * 4;
+  return nb * I * (b + a / c) + tfix * nb / c + slab_b / 11.7e6 + (3.0 + 1.5 * cs) + 10.0;
+}
 
 // Cost of one schedule (us), fitted to 477 forced-schedule timings of this kernel (tools/wino2_plan_sweep.py, profiles/r3_wino2d_plan_sweep.log:
 // five layer shapes x 16 / 32 / 64 images x both k blocks x 21 (main slices, tail slices) settings, rms error 9 %).  A CU's busiest set of
@@ -447,6 +565,26 @@ W2Plan wino2_plan(long M4, int Nc, int C) {
   if (best_t == 1e300) {                                                   // (forced settings the shape does not allow)
     const int bk = (e_bk == 32 && C % 32 == 0) ? 32 : 16;
     best.t_us = w2_cost(T, gn, M4, Nc, 16L * (C / bk), bk, 1, 1, &best);
+    best_t = best.t_us;
+  }
+  // the position-split instantiation (small grids): NNL_WINO2_POS = -1 (default) by predicted time, 0 never, n > 0 forces n channel slices
+  const int e_pos = NNL_ENV_INT("NNL_WINO2_POS", -1);
+  if (e_pos != 0 && C % 32 == 0 && (e_bk == 0 || e_bk == 32)) {
+    const int csteps = C / 32;
+    double pt = 1e300; int pcs = 0;
+    for (int cs = 1; cs <= 8; cs *= 2) {
+      if (csteps % cs != 0 || (csteps / cs < 2 && cs > 1)) break;
+      if (e_pos > 0 && cs != e_pos && csteps % e_pos == 0) continue;
+      const size_t fl = (size_t)16 * cs * M4 * Nc;
+      if (fl * sizeof(float) >= (1UL << 31)) break;
+      const double t = w2_pos_cost(T, M4, Nc, C, cs);
+      if (t < pt) { pt = t; pcs = cs; }
+    }
+    if (pcs && (e_pos > 0 || pt < best_t)) {
+      best = W2Plan{};
+      best.bk = 32; best.on = 1; best.main_ks = 16 * pcs; best.n_main_tiles = (int)T; best.tail_slices = 1; best.tail_row0 = (int)M4;
+      best.main_floats = (size_t)16 * pcs * M4 * Nc; best.tail_floats = 0; best.t_us = pt; best.pos_cs = pcs;
+    }
   }
   return best;
 }
@@ -502,9 +640,23 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
   const long T = (long)p.grid_m * p.grid_n;
   W2Plan pl = wino2_plan(M4, q.Nc, q.Cin);
   if (pl.on && (tile_counters == nullptr || T > n_counters || ws_bytes < (u_floats + pl.main_floats + pl.tail_floats) * sizeof(float) ||
-                pl.main_floats * sizeof(float) >= (1UL << 31) || pl.tail_floats * sizeof(float) >= (1UL << 31)))
+                pl.main_floats * sizeof(float) >= (1UL << 31) || pl.tail_floats * sizeof(float) >= (1UL << 31))) {
+    if (pl.pos_cs) {                                                       // (no counters / workspace for the slabs: the unsplit plan)
+      const int bk = q.Cin % 32 == 0 ? 32 : 16;
+      w2_cost(T, p.grid_n, M4, q.Nc, 16L * (q.Cin / bk), bk, 1, 1, &pl);
+      pl.pos_cs = 0;
+    }
     pl.on = 0;
+  }
   unsigned grid = (unsigned)T;
+  if (pl.pos_cs) {
+    p.bal = 1; p.main_ks = pl.main_ks; p.n_main_tiles = pl.n_main_tiles; p.tail_slices = 1; p.tail_row0 = (int)M4;
+    p.main_out = u + u_floats; p.main_slab_stride = M4 * q.Nc; p.tile_counters = tile_counters; p.pos_cs = pl.pos_cs;
+    grid = (unsigned)(T * pl.main_ks);
+    hipLaunchKernelGGL((wino2_kernel<32, 4, true>), dim3(grid), dim3(256), 0, s, p);
+    NNL_CHECK_LAUNCH();
+    return NNL_OK;
+  }
   if (pl.on) {
     p.bal = 1; p.main_ks = pl.main_ks; p.n_main_tiles = pl.n_main_tiles; p.tail_slices = pl.tail_slices; p.tail_row0 = pl.tail_row0;
     p.main_out = u + u_floats; p.main_slab_stride = (long)pl.tail_row0 * 4 * q.Nc;

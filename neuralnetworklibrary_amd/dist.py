@@ -136,8 +136,18 @@ class GradSync:
                 self._use_counts.append(p._nnl_uses)
         self._active = False
         self.capturing = False                          # Learner.use_graphs under DP: hooks fill the buckets, collectives run after the replay
-        self.overlap = None                             # _ReplayOverlap once a step has been captured with per-bucket signals (GPU only)
-        self.overlap_launches = 0                       # collectives that were enqueued behind a wait kernel (diagnostics)
+        # the replay-overlap protocol's device words + side stream: ONE set per GradSync, shared by every captured step (Learner keeps
+        # up to four graphs per GradSync, e.g. the full and the ragged last minibatch) — the step word the graphs bump and the host's
+        # replay counter are global, so the flags of whichever graph ran last are comparable with the next wait.  Captured kernels
+        # hold raw pointers into `words`: the tensor is never replaced while this object lives (a rebuild with more buckets than its
+        # capacity retires it into `_retired_overlaps`, which keeps the memory alive for graphs that may still be replayed)
+        ov = getattr(self, 'overlap', None)
+        if ov is not None and ov.capacity < len(self.buckets):
+            self._retired_overlaps = getattr(self, '_retired_overlaps', []) + [ov]
+            ov = None
+        self.overlap = ov                               # created by prepare_overlap() (GPU only)
+        self.overlap_ok = True                          # False after a wait kernel's time-out: later replays reduce after the replay
+        self.overlap_launches, self.last_signalled = 0, None   # collectives enqueued behind a wait kernel / signals of the last replayed graph (diagnostics)
         self.weight = 1.0
         self.direct_writes, self.steps = 0, 0           # gradients that arrived in place / backward passes (diagnostics)
 
@@ -186,7 +196,7 @@ class GradSync:
             # queue get their flag words set and a SIGNAL kernel (csrc/runtime.hip: nnl_dp_signal) right here — i.e. at the point of
             # the captured backward where their last gradient has been written — so that reduce_overlapped() can start bucket k's
             # all-reduce in the MIDDLE of each replay (strictly in bucket order, as the eager path)
-            if self.overlap is not None:
+            if self._capture_overlap:
                 while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
                     bk = self.buckets[self._next]
                     bk.flags.fill_(1.0)
@@ -204,47 +214,55 @@ class GradSync:
         stream of the replay-overlap protocol.  Not available on CPU tensors (the gloo tests) or with NNL_DIST_REPLAY_OVERLAP=0: then
         reduce_all() is the replay path."""
         dev = self.buckets[0].flat.device if self.buckets else None
-        if dev is None or dev.type != 'cuda' or os.environ.get('NNL_DIST_REPLAY_OVERLAP', '1') == '0':
-            self.overlap = None
-        else:
+        self._capture_overlap = not (dev is None or dev.type != 'cuda' or os.environ.get('NNL_DIST_REPLAY_OVERLAP', '1') == '0')
+        if self._capture_overlap and self.overlap is None:
             self.overlap = _ReplayOverlap(len(self.buckets), dev)
         self._next = 0
 
+    _capture_overlap = False
+
     def capture_begin(self):
         "first thing INSIDE the capture (Learner._GraphedStep): the replay counter's bump"
-        if self.overlap is not None:
+        if self._capture_overlap:
             self.overlap.bump()
 
     def capture_end(self):
-        "which buckets got a signal in the captured backward (the others — parameters without a gradient — are reduced after the replay)"
-        if self.overlap is not None:
-            self.overlap.signalled = self._next
-        self._next = 0
+        """-> how many buckets got a signal in the captured backward (the others — parameters without a gradient — are reduced after the
+        replay), or None when the capture carries no overlap protocol.  The captured step keeps the number and hands it to
+        reduce_overlapped(): it belongs to THAT graph, not to the GradSync."""
+        signalled = self._next if self._capture_overlap else None
+        self._next, self._capture_overlap = 0, False
+        return signalled
 
-    def reduce_overlapped(self, weight=1.0):
+    def reduce_overlapped(self, weight=1.0, signalled=None):
         """After a captured forward + backward has been ENQUEUED (graph.replay() returned): for every bucket, in order, a wait kernel on the
         side stream (until the replay's signal for that bucket) followed by its all-reduce — the collectives of the early buckets run
-        under the rest of the replayed backward; buckets that completed without a signal wait for the whole replay.  Then finish()."""
+        under the rest of the replayed backward; buckets that completed without a signal wait for the whole replay.  Then finish().
+        signalled: capture_end()'s value for the graph that was just replayed."""
         ov = self.overlap
-        if ov is None:
+        if ov is None or signalled is None:
             return self.reduce_all(weight)
+        ov.replays += 1                                   # the graph bumped the device step word: keep the host's count in step ALWAYS
+        if not self.overlap_ok:
+            return self.reduce_all(weight)                # after a time-out: the round-3 behaviour (collectives behind the whole replay)
         self._active, self.weight, self._next = True, float(weight), 0
-        ov.replays += 1
+        self.last_signalled = signalled
         main = torch.cuda.current_stream()
         for k, b in enumerate(self.buckets):
             b.pending, b.ready, b.handle, b.averaged = 0, [True] * len(b.params), None, False
-            if k < ov.signalled:
+            if k < signalled:
                 ov.wait(k)                                # enqueued on ov.side
             else:
                 ov.side.wait_stream(main)                 # no signal in the capture: after the whole replay
             with torch.cuda.stream(ov.side):
-                if k >= ov.signalled:
+                if k >= signalled:
                     b.flags.fill_(1.0)
                 self._launch_filled(b)
-            self.overlap_launches += int(k < ov.signalled)
+            self.overlap_launches += int(k < signalled)
         self._next = len(self.buckets)
         main.wait_stream(ov.side)                         # (the averaged buckets are consumed on the main stream)
         self.finish()
+        ov.stage_err()                                    # async copy of the error word behind this step's work (checked with the loss)
 
     def _launch_filled(self, b):
         "the collective of a bucket whose flag words are already set (replay path)"
@@ -255,10 +273,26 @@ class GradSync:
             op = dist.ReduceOp.AVG if b.averaged else dist.ReduceOp.SUM
             b.handle = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
 
-    def raise_if_overlap_error(self):
-        "a wait kernel of the replay path ran into its poll bound (the signal never came): surfaced at the same points as index errors"
-        if self.overlap is not None and int(self.overlap.err.item()) != 0:
-            raise RuntimeError('data-parallel replay: a bucket wait kernel timed out (no signal from the captured backward)')
+    def raise_if_overlap_error(self, synced=False):
+        """A wait kernel of the replay path ran into its time bound (the signal never came): the bucket's all-reduce then ran on
+        partially written gradients and the optimizer stepped on them — raise at once.  Called right after the per-step `loss.item()`
+        of a replayed data-parallel step (synced=True: the error word's pinned copy was enqueued before that sync, no second one) and at
+        epoch end.  The word is reset and later replays reduce after the whole replay (no wait kernels), so a caller that catches the
+        error can go on."""
+        ov = self.overlap
+        if ov is None:
+            return
+        if synced and ov.host_err is not None:
+            bad = int(ov.host_err[0]) != 0
+        else:
+            bad = int(ov.err.item()) != 0
+        if bad:
+            ov.err.zero_()
+            if ov.host_err is not None:
+                ov.host_err.zero_()
+            self.overlap_ok = False
+            raise RuntimeError('data-parallel replay: a bucket wait kernel timed out (no signal from the captured backward within '
+                               '%.0f s); the step used incomplete gradients' % (ov.timeout_us * 1e-6))
 
     def reduce_all(self, weight=1.0):
         """After the replay of a captured forward + backward (which filled every bucket): all-reduce all buckets now, in order."""
@@ -310,11 +344,16 @@ class _ReplayOverlap:
     def __init__(self, n_buckets, device):
         from . import _lib
         self._lib = _lib
-        self.words = torch.zeros(n_buckets + 2, dtype=torch.int32, device=device)      # [step, err, flag_0 ... flag_{n-1}]
+        self.capacity = max(int(n_buckets), 64)
+        self.words = torch.zeros(self.capacity + 2, dtype=torch.int32, device=device)  # [step, err, flag_0 ... flag_{n-1}]
         self.step, self.err, self.flags = self.words[0:1], self.words[1:2], self.words[2:]
         self.side = torch.cuda.Stream(device=device)
-        self.replays, self.signalled = 0, 0
-        self.max_polls = int(os.environ.get('NNL_DIST_WAIT_POLLS', 4000000))          # x ~0.3 us per poll: ~1 s
+        self.replays = 0                                                               # host mirror of the device step word
+        self.timeout_us = int(float(os.environ.get('NNL_DIST_WAIT_SECONDS', 60)) * 1e6)   # wall time (device clock), not polls
+        self.host_err = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    def stage_err(self):
+        self.host_err.copy_(self.err, non_blocking=True)
 
     def _s(self):
         return torch.cuda.current_stream().cuda_stream
@@ -326,7 +365,7 @@ class _ReplayOverlap:
         self._lib.check(self._lib.lib.nnl_dp_signal(self.flags[k:k + 1].data_ptr(), self.step.data_ptr(), self._s()))
 
     def wait(self, k):
-        self._lib.check(self._lib.lib.nnl_dp_wait(self.flags[k:k + 1].data_ptr(), self.replays, self.max_polls, self.err.data_ptr(), self.side.cuda_stream))
+        self._lib.check(self._lib.lib.nnl_dp_wait(self.flags[k:k + 1].data_ptr(), self.replays, self.timeout_us, self.err.data_ptr(), self.side.cuda_stream))
 
 
 class ShardedBatches:

@@ -178,8 +178,9 @@ def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
         assert n1 == 0 and n2 == 1 and n3 == 1
         # round 4: the captured backward carries one signal kernel per bucket; every replay's collectives were enqueued behind wait kernels
         # on the side stream (7 replays — the capture step's own and six more — x all buckets), none timed out; with the overlap switched off they follow the whole replay
-        assert g2.overlap is not None and g2.overlap.signalled == len(g2.buckets) and g2.overlap_launches == 7 * len(g2.buckets)
-        assert int(g2.overlap.flags.min().item()) == g2.overlap.replays == 7 and int(g2.overlap.step.item()) == 7
+        nb = len(g2.buckets)
+        assert g2.overlap is not None and g2.last_signalled == nb and g2.overlap_launches == 7 * nb
+        assert int(g2.overlap.flags[:nb].min().item()) == g2.overlap.replays == 7 and int(g2.overlap.step.item()) == 7
         assert g3.overlap is None and g3.overlap_launches == 0
         assert_close(l1, l0, 1e-5, 1e-6, 'eager DP vs eager')
         assert_close(l2, l1, 1e-5, 1e-6, 'graph DP (overlapped collectives) vs eager DP')
@@ -192,6 +193,96 @@ def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
         nd._FORCE_ALLREDUCE = forced
         if created:
             dist.destroy_process_group()
+
+
+def test_graph_replay_under_data_parallelism_with_two_input_signatures():
+    """under data parallelism the ragged last minibatch gives a second per-rank input shape, so a second graph is
+    captured next to the first.  Both graphs must share ONE set of protocol words (step counter, flags) — the first version replaced
+    them at the second capture: the first graph's signal kernels then wrote into freed memory and every later wait spun to its bound.
+    Here the two shapes alternate for 16 steps; the run must train like eager DP, every replay's collectives must have gone out
+    behind wait kernels and no wait may have timed out."""
+    import os
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29534')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    forced = nd._FORCE_ALLREDUCE
+    nd._FORCE_ALLREDUCE = True
+    try:
+        S = 64
+        g = torch.Generator().manual_seed(7)
+        batches = [(torch.randn(n, 3, S, S, generator=g).to(DEV), torch.randint(0, 2, (n,), generator=g).to(DEV)) for n in (8, 6, 8, 6)]
+
+        class D:
+            sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, 8, 'single_label'
+            train_dl = val_dl = batches
+
+        def run(graphs):
+            torch.manual_seed(0)
+            net = V.ImageClassificationNet(D, V.models.resnet18(), head=[[64], [0., 0.]])
+            learner = Learner('/tmp/nnl_graph_test', D, net, optimizer='SGD_Mom')
+            learner.init_optimizer(wd=1e-4)
+            learner.distribute(bucket_mb=8.0, equal_shards=True)
+            if graphs:
+                learner.use_graphs(True, warmup=2)
+            net.train()
+            losses = [learner.train1minibatch(*batches[i % 4], [1e-3, 2e-3, 5e-3], mom_batch=0.9) for i in range(16)]
+            learner.grad_sync.raise_if_overlap_error()
+            return np.array(losses), [p.detach().cpu().numpy().copy() for p in net.parameters()], learner
+        le, pe, _ = run(False)
+        lg, pg, learner = run(True)
+        gs = learner.grad_sync
+        graphs = [v for v in learner._graphs.values() if v.graph is not None]
+        assert len(graphs) == 2
+        nb = len(gs.buckets)
+        # 16 steps = 2 signatures x (2 eager warm-ups + 6 replays, the capture step's own included)
+        assert gs.overlap.replays == 12 and int(gs.overlap.step.item()) == 12 and gs.overlap_launches == 12 * nb
+        assert int(gs.overlap.flags[:nb].min().item()) == 12 and int(gs.overlap.err.item()) == 0
+        assert all(v.signalled == nb for v in graphs)
+        assert_close(lg, le, 1e-5, 1e-6, 'graph DP with two signatures vs eager DP')
+        for a, b in zip(pg, pe):
+            assert_close(a, b, 1e-4, 1e-6, 'params')
+    finally:
+        nd._FORCE_ALLREDUCE = forced
+        if created:
+            dist.destroy_process_group()
+
+
+def test_replay_overlap_wait_times_out_loudly_and_falls_back():
+    """a wait kernel whose signal never comes must not let training go on silently — its time bound is WALL time
+    (device clock), the error is raised at the step's own loss read-back, the word is reset and later replays reduce after the
+    whole replay.  Driven directly: a wait for a flag value that nobody publishes, with a 20 ms bound."""
+    from neuralnetworklibrary_amd import dist as nd
+    import time
+    lin = torch.nn.Linear(8, 8).to(DEV)
+    gs = nd.GradSync(lin, bucket_mb=1.0)
+    gs.prepare_overlap()
+    gs.capture_end()
+    ov = gs.overlap
+    assert ov is not None
+    ov.timeout_us = 20000
+    ov.replays = 5                                          # nobody bumped the device step word / set the flag to 5
+    t0 = time.time()
+    ov.wait(0)
+    ov.side.synchronize()
+    dt = time.time() - t0
+    assert 0.015 < dt < 5.0, dt                             # the bound is time, not a poll count
+    torch.cuda.current_stream().wait_stream(ov.side)
+    ov.stage_err()
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match='timed out'):
+        gs.raise_if_overlap_error(synced=True)
+    assert gs.overlap_ok is False and int(ov.err.item()) == 0
+    gs.raise_if_overlap_error()                             # reset: nothing to raise any more
 
 
 def test_keyed_dropout_keeps_the_step_eager():
