@@ -22,6 +22,7 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
 // the 2-D F(2x2, 3x3) variant (wino2.hip): rows are 2x2 output quads, U is [Nc][16][Cin]; same problem struct
 bool nnl_wino2_ok(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad);
 double nnl_wino2_plan_time_us(int N, int H, int W, int Cin, int Nc);
+bool nnl_wino2_plan_is_pos(int N, int H, int W, int Cin, int Nc);      // the plan is the position-split (small-grid) instantiation
 size_t nnl_wino2_workspace_bytes(int N, int H, int W, int Cin, int Nc);
 int nnl_wino2_bn_rows(int N, int H, int W);
 int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_counters, long n_counters, hipStream_t s);

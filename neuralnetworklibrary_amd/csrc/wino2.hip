@@ -28,6 +28,13 @@ namespace {
 
 constexpr int kCUs = 256;
 
+// sc1 (device-scope) 16-B load with the wave-uniform part of the address in the scalar offset operand (no VGPR per distinct slab)
+template <int POL>
+__device__ __forceinline__ f32x4 buf_load4_spol(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, POL));
+  return __builtin_bit_cast(f32x4, v);
+}
+
 struct Wino2Params {
   const float* a;      // in [N][H][W][C]
   const float* b;      // U  [Nc][16][C]
@@ -193,8 +200,31 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
   // measured SLOWER (NNL_WINO2_CHUNK=64: 28^2 stage -5 %, 14^2 stage -7 %, profiles/r3_wino2d_chunk_ab_bs64.log): the re-reads hit the
   // Infinity Cache and are not what bounds the loop.
   const int csteps = p.C / BK, nk_all = 16 * csteps, cpc = p.ch / BK, per_chunk = 16 * cpc;
+  if constexpr (POS) {
+    // ONE position, a channel slice of it: offsets and signs are fixed for the whole loop, only the channel offset advances.  (A second
+    // staging register set — two tiles in flight — measured no better at 8 images and 10 % worse at 32, where it costs the fourth
+    // co-resident workgroup: profiles/r5_wino2_pos_*.log.)
+    const int t_pos = kslice / p.pos_cs, sub = kslice - t_pos * p.pos_cs, nkb = csteps / p.pos_cs;
+    set_pos(t_pos);
+    sr_ld = sr; sc_ld = sc;
+    const int cb0 = sub * nkb * BK;
+    load_tile(cb0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkb; ++kt) {
+      if (kt + 1 < nkb) load_tile(cb0 + (kt + 1) * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, tm);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nkb) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
   int kt0 = 0, nk = nk_all;
-  if (partial) {
+  if (POS) nk = 0;
+  else if (partial) {
     const int per = (nk_all + nslices - 1) / nslices;
     kt0 = kslice * per;
     nk = min(per, nk_all - kt0);
@@ -233,7 +263,6 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
-    if constexpr (POS) continue;                       // one position per workgroup: tm IS the slice's share of M_t
     if (++cs_cur == cpc || kt + 1 == kend) {          // the position's blocks of this chunk (or this slice of them) are done: fold tm in
       const int xi = t_cur >> 2, nu = t_cur & 3;
       const float cp0 = xi < 3 ? 1.f : 0.f, cp1 = xi == 0 ? 0.f : (xi == 2 ? -1.f : 1.f);
@@ -288,24 +317,15 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
     float fs1[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
     const int c4 = n0 + (tid & 15) * 4, cs = p.pos_cs;
     const int wrow = p.W * p.Nc;
-    for (int k4 = 0; k4 < 4; ++k4) {
+    // this thread's four (quad row, 4-column) items, one at a time with its 16 slab loads in flight (two at a time needs 168 VGPRs: slower)
+    auto item_off = [&](int k4, bool& ok) {
       const int row = m0 + (tid >> 4) + 16 * k4;
-      if (row >= p.M4 || c4 >= p.Nc) continue;
-      const unsigned o0 = (unsigned)(((long)row * p.Nc + c4) * 4);
-      f32x4 m[16];
-#pragma unroll
-      for (int t = 0; t < 16; ++t) m[t] = buf_load4_pol(rs, o0 + (unsigned)((long)(t * cs) * sstride * 4), kSc1);     // 16 loads in flight
-      for (int sl = 1; sl < cs; ++sl) {
-#pragma unroll
-        for (int t0 = 0; t0 < 16; t0 += 8) {                   // (eight at a time: 16 more float4 would spill at four workgroups per CU)
-          f32x4 part[8];
-#pragma unroll
-          for (int t = 0; t < 8; ++t) part[t] = buf_load4_pol(rs, o0 + (unsigned)((long)((t0 + t) * cs + sl) * sstride * 4), kSc1);
-#pragma unroll
-          for (int t = 0; t < 8; ++t) m[t0 + t] += part[t];
-        }
-      }
-      // A^T M A: rows first (r0 = m0 + m1 + m2, r1 = m1 - m2 + m3 over nu), then the same pattern over xi
+      ok = row < p.M4 && c4 < p.Nc;
+      return ok ? (unsigned)(((long)row * p.Nc + c4) * 4) : 0xFFFFFFFFu;
+    };
+    auto finish_item = [&](int k4, f32x4 (&m)[16]) {
+      const int row = m0 + (tid >> 4) + 16 * k4;
+      // A^T M A: over nu first (r0 = m0 + m1 + m2, r1 = m1 - m2 + m3), then the same pattern over xi
       f32x4 r0[4], r1[4];
 #pragma unroll
       for (int xi = 0; xi < 4; ++xi) {
@@ -336,6 +356,26 @@ __global__ __launch_bounds__(256, OCC) void wino2_kernel(const Wino2Params p) {
           for (int e = 0; e < 4; ++e) { const float d = v[e] - pv[e]; fs1[e] += d; fs2[e] += d * d; }
         }
       }
+    };
+#pragma unroll 1
+    for (int k4 = 0; k4 < 4; ++k4) {
+      bool ok_a;
+      const unsigned oa = item_off(k4, ok_a);
+      if (!ok_a) continue;
+      f32x4 ma[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) ma[t] = buf_load4_spol<kSc1>(rs, oa, (unsigned)((long)(t * cs) * sstride * 4));      // 16 loads in flight
+      for (int sl = 1; sl < cs; ++sl) {
+#pragma unroll
+        for (int t0 = 0; t0 < 16; t0 += 8) {
+          f32x4 pa[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) pa[t] = buf_load4_spol<kSc1>(rs, oa, (unsigned)((long)((t0 + t) * cs + sl) * sstride * 4));
+#pragma unroll
+          for (int t = 0; t < 8; ++t) ma[t0 + t] += pa[t];
+        }
+      }
+      finish_item(k4, ma);
     }
     if (p.bn_part) {
       __syncthreads();
@@ -603,6 +643,7 @@ bool nnl_wino2_ok(int N, int H, int W, int Cin, int Nc, int R, int S, int stride
 }
 
 double nnl_wino2_plan_time_us(int N, int H, int W, int Cin, int Nc) { return wino2_plan(quads(N, H, W), Nc, Cin).t_us; }
+bool nnl_wino2_plan_is_pos(int N, int H, int W, int Cin, int Nc) { return wino2_plan(quads(N, H, W), Nc, Cin).pos_cs > 0; }
 
 size_t nnl_wino2_workspace_bytes(int N, int H, int W, int Cin, int Nc) {
   const W2Plan pl = wino2_plan(quads(N, H, W), Nc, Cin);

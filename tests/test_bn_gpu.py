@@ -19,6 +19,10 @@ CASES = [  # shape, residual, relu, training, mean offset
     ((8, 1024), False, False, True, 0.0),
     ((4, 64, 14, 14), True, True, False, 0.0),     # eval mode (frozen BN)
     ((5, 20, 3, 3), False, True, False, 1.0),
+    ((8, 64, 56, 56), True, True, True, 0.5),      # ResNet-34 stages at 8 images per GPU (the strong-scaling regime)
+    ((8, 512, 7, 7), True, True, True, 0.0),
+    ((16, 256, 14, 14), False, True, True, 2.0),
+    ((2, 2048, 4, 4), True, True, True, 0.0),      # ResNet-50's widest layer
 ]
 
 

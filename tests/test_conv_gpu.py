@@ -466,9 +466,25 @@ def test_winograd_2d_debug_entry(case, chunk, monkeypatch):
     """The 2-D F(2x2, 3x3) kernel (csrc/wino2.hip) through its debug entry nnl_debug_conv_wino2_fwd (the dispatcher takes it from ~500
     quad tiles up; profiles/README.md has the measurements): forward with bias / addend / ReLU / BatchNorm partial sums and the flipped dgrad
     filter, odd heights and widths, plain grid and forced k-slicing (in-kernel slab fix-up), against torch CPU fp32."""
+    _winograd_2d_debug_entry(case, chunk, '0', monkeypatch)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 12, 10, 64, None), (8, 512, 7, 7, 512, None), (4, 128, 14, 14, 128, None), (1, 32, 2, 2, 32, None),
+                                  (2, 64, 17, 33, 96, None), (8, 256, 14, 14, 256, None)], ids=str)
+@pytest.mark.parametrize('pos', ['1', '2', '4'], ids=['cs1', 'cs2', 'cs4'])
+def test_winograd_2d_position_split(case, pos, monkeypatch):
+    """Round 5, the small-grid mode of the 2-D kernel (wino2_kernel<32, 4, POS>): one position (xi, nu) — or a channel slice of one — per
+    workgroup, M slabs, the tile's last arriver applies A^T M A.  Forced with NNL_WINO2_POS = channel slices per position (a count the
+    shape does not allow falls back to the planner's pick); the same checks as the debug-entry test, incl. the ResNet-34 14^2 / 7^2 stages
+    at 8 images (the shapes it was built for), odd sizes, BatchNorm partials, bitwise repeatability and counters back to zero."""
+    _winograd_2d_debug_entry(case, '0', pos, monkeypatch)
+
+
+def _winograd_2d_debug_entry(case, chunk, pos, monkeypatch):
     from neuralnetworklibrary_amd._lib import lib, ptr, stream, check
     N, C, H, W, K, forced = case
     monkeypatch.setenv('NNL_WINO2_CHUNK', chunk)              # k order: whole C per position (default) / 32-channel chunks outermost
+    monkeypatch.setenv('NNL_WINO2_POS', pos)                  # 0: never the position-split instantiation; n: n channel slices per position
     if forced:
         monkeypatch.setenv('NNL_WINO_PLAN_KS', str(forced[0])); monkeypatch.setenv('NNL_WINO_PLAN_S', str(forced[1]))
     lib.nnl_reload_env()
@@ -515,5 +531,5 @@ def test_winograd_2d_debug_entry(case, chunk, monkeypatch):
         assert_close(dx, refdx, rtol=1e-4, atol=1e-5 * refdx.abs().max().item(), msg='2-D Winograd dgrad filter')
     if forced:
         monkeypatch.delenv('NNL_WINO_PLAN_KS'); monkeypatch.delenv('NNL_WINO_PLAN_S')
-    monkeypatch.delenv('NNL_WINO2_CHUNK')
+    monkeypatch.delenv('NNL_WINO2_CHUNK'); monkeypatch.delenv('NNL_WINO2_POS')
     lib.nnl_reload_env()

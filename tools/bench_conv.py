@@ -61,6 +61,7 @@ def ab(args):
     import statistics
     var, vals = args.ab.split('=')
     vals = vals.split(',')
+    names = var.split('+')                          # several variables per setting: "A+B=0+1,3+2" sets A=0 B=1, then A=3 B=2
     dev, N = 'cuda', args.bs
     print('%-10s %-6s ' % ('layer', 'pass') + ' '.join('%s=%-4s ms   TF/s |' % (var[-6:], v) for v in vals))
     totals = {v: 0.0 for v in vals}
@@ -81,7 +82,8 @@ def ab(args):
             res = {v: [] for v in vals}
             for _ in range(5):
                 for v in vals:
-                    os.environ[var] = v
+                    for nm, vv in zip(names, v.split('+')):
+                        os.environ[nm] = vv
                     _lib.lib.nnl_reload_env()
                     res[v].append(timeit(fn, iters=5))
             med = {v: statistics.median(res[v]) for v in vals}
@@ -95,11 +97,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bs', type=int, default=64)
     ap.add_argument('--net', default='r34', help="'r34' (ResNet-34 at 224, default) or 'r50' (RetinaNet R50-FPN at 512)")
-    ap.add_argument('--ab', default=None, help='A/B in ONE process, interleaved: ENVVAR=v0,v1[,v2] (e.g. NNL_IGEMM_BK32=0,1)')
+    ap.add_argument('--ab', default=None, help='A/B in ONE process, interleaved: ENVVAR=v0,v1[,v2] (e.g. NNL_IGEMM_BK32=0,1); several variables per setting: A+B=0+1,3+2')
+    ap.add_argument('--only', default=None, help='comma-separated layer-name substrings to keep (e.g. 3x3)')
     args = ap.parse_args()
     global LAYERS
     if args.net == 'r50':
         LAYERS = LAYERS_R50
+    if args.only:
+        LAYERS = [l for l in LAYERS if any(k in l[0] for k in args.only.split(','))]
     if args.ab:
         return ab(args)
     dev = 'cuda'
