@@ -334,16 +334,56 @@ def committed_counters(bs, sz, world):
     profiled.  Reported only for the configuration those passes profiled AND only while the loaded library still carries that stamp
     (nnl_source_stamp): after any kernel change the figures read null until the passes are re-run — they cannot go stale silently."""
     from neuralnetworklibrary_amd import _lib
+    name = next((n for n in ('r5_traffic.json', 'r4_traffic.json') if os.path.exists(os.path.join(ROOT, 'profiles', n))), None)
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r4_traffic.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
             t = json.load(f)
     except Exception:
         return None, None, 'no committed counter passes'
     if (bs, sz, world) != (t.get('bs', 64), t.get('sz', 224), t.get('gpus', 1)):
         return None, None, 'counter passes exist for another configuration only'
     if t.get('source_stamp') != _lib.source_stamp():
-        return None, None, 'profiles/r4_traffic.json was measured on source stamp %s, this library is %s: re-run tools/gpu/r4_counters.sh' % (t.get('source_stamp'), _lib.source_stamp())
-    return round(t['traffic_bytes_per_launch']), t.get('mfma_busy'), 'profiles/r4_traffic.json (rocprofv3 --pmc passes of this command on this very build, source stamp %s; committed figures, not measured in this run)' % t['source_stamp']
+        return None, None, ('profiles/%s was measured on source stamp %s, this library is %s: re-run tools/gpu/r5_counters.sh (or bench.py --counters)'
+                            % (name, t.get('source_stamp'), _lib.source_stamp()))
+    return round(t['traffic_bytes_per_launch']), t.get('mfma_busy'), ('profiles/%s (rocprofv3 --pmc passes of this command on this very build, source stamp %s; '
+                                                                       'committed figures, not measured in this run)' % (name, t['source_stamp']))
+
+
+def measured_counters(args):
+    """--counters (opt-in, N = 1): the three PMC passes the committed figures come from, taken NOW on the loaded library — each pass a FRESH child
+    process `rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    --no-sweep --configs none` (subprocess: the GPU-holding parent is not replaced; `python3` directly after `--`, no env / shell hop;
+    counters in their own runs, never with trace domains).  ~1 min per pass.  Summarised by tools/pmc_traffic.py (gfx950 corrections)."""
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return {'error': 'rocprofv3 not on PATH'}
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_traffic
+    base = tempfile.mkdtemp(prefix='nnl_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    csvs = {}
+    try:
+        for tag, counters in (('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']), ('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE'])):
+            d = os.path.join(base, tag)
+            cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', tag, '--', 'python3', os.path.abspath(__file__),
+                                                       '--steps', '3', '--warmup', '1', '--bs', str(args.bs), '--sz', str(args.sz), '--no-cpu-baseline', '--no-sweep',
+                                                       '--configs', 'none']
+            r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=900)
+            found = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+            if r.returncode != 0 or not found:
+                return {'error': 'rocprofv3 --pmc %s failed (rc %s): %s' % (' '.join(counters), r.returncode, (r.stderr or '')[-300:])}
+            csvs[tag] = found[0]
+        js = pmc_traffic.main(csvs['fetch'], csvs['write'], 'live', csvs['mfma'], None, write_files=False)
+        return {'traffic': round(js['traffic_bytes_per_launch']), 'mfma_busy': js.get('mfma_busy'),
+                'fetch_size_bytes_per_launch_raw': round(js['fetch_size_bytes_per_launch_raw']), 'write_size_bytes_per_launch': round(js['write_size_bytes_per_launch']),
+                'source': 'measured by this run: three rocprofv3 --pmc child passes of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none` '
+                          'on the loaded library (FETCH_SIZE x2 per the gfx950 note, WRITE_SIZE exact; per conv / linear GEMM launch)'}
+    except Exception as e:                               # noqa: BLE001 — diagnostics must not take the JSON line down
+        return {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
 
 
 def host_info():
@@ -360,12 +400,60 @@ def host_info():
 
 
 # ---- CPU baselines: the oracle's restatement of the same step on the host cores (rank 0, N = 1 only) ------------------
+def cpu_share():
+    """The host share this process really has: the GPU boxes run under a cgroup CPU QUOTA (cpu.max 1600000 / 100000 = 16 CPUs' worth of
+    time on a 256-core host, tools/cpu_threads_probe.py) — more OpenMP threads than that are throttled by the scheduler, which is why
+    32 / 64 threads measured 9 - 18x SLOWER in round 4.  -> {'threads': min(affinity, quota), 'affinity': ..., 'quota_cpus': ... or None}"""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                      # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != 'max':
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    n = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return {'threads': n, 'affinity': aff, 'quota_cpus': quota}
+
+
 def _cpu_threads():
-    # the GPU box shares its host: 16 cores is the CPU share of a 1-GPU slot (more threads thrash: 256 threads measured
-    # 116 s/step vs ~4 s/step on 8 cores)
-    n = min(os.cpu_count() or 1, 16)
+    # inside the baseline child the thread count comes from the parent (NNL_BENCH_CPU_THREADS); otherwise the quota / affinity share, at most 64
+    n = int(os.environ.get('NNL_BENCH_CPU_THREADS', 0)) or min(cpu_share()['threads'], 64)
     torch.set_num_threads(n)
     return n
+
+
+def cpu_baseline_child(name, bs, sz):
+    """Run one CPU baseline in a FRESH child process: its OpenMP pool is created with OMP_NUM_THREADS = the host share and bound to cores
+    (OMP_PROC_BIND=close, OMP_PLACES=cores: +19 % on the ResNet-34 step at 16 threads, tools/cpu_threads_probe.py) — a binding has to be
+    in the environment before the runtime starts, hence the child.  The child never touches the GPU.  (subprocess = fork + exec of a
+    CHILD; the GPU-holding parent is not replaced.)"""
+    share = cpu_share()
+    n = min(share['threads'], 64)
+    env = dict(os.environ, OMP_NUM_THREADS=str(n), MKL_NUM_THREADS=str(n), OMP_PROC_BIND='close', OMP_PLACES='cores', NNL_BENCH_CPU_THREADS=str(n),
+               HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-child', name, '--bs', str(bs), '--sz', str(sz)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'error': 'cpu baseline child failed (rc %s): %s' % (r.returncode, (r.stderr or r.stdout)[-300:])}
+    out = json.loads(lines[-1])
+    out['cpu_share'] = share
+    out['binding'] = 'OMP_PROC_BIND=close OMP_PLACES=cores, fresh process'
+    return out
+
+
+def cpu_baseline_child_main(name, bs, sz):
+    fn = {'resnet': lambda: cpu_baseline_resnet(bs, sz), 'collab': lambda: cpu_baseline_collab(64), 'tabular': lambda: cpu_baseline_tabular(1024),
+          'lm': cpu_baseline_lm, 'retinanet': cpu_baseline_retina}[name]
+    print(json.dumps(fn()), flush=True)
 
 
 def _cpu_time(step, steps):
@@ -380,32 +468,13 @@ def _sgd_adam_step(RM, params, state, kind, lr, wd, **kw):
     RM.optimizer_step(params, [p.grad for p in params], state, [lr] * len(params), [wd] * len(params), kind, **kw)
 
 
-def _pin_process(cpus):
-    "affinity of EVERY thread of this process (the OpenMP pool exists already) -> cpus; returns the previous masks"
-    old = {}
-    for tid in os.listdir('/proc/self/task'):
-        try:
-            old[int(tid)] = os.sched_getaffinity(int(tid))
-            os.sched_setaffinity(int(tid), cpus)
-        except OSError:
-            pass
-    return old
-
-
-def _unpin_process(old):
-    for tid, mask in old.items():
-        try:
-            os.sched_setaffinity(tid, mask)
-        except OSError:
-            pass
-
-
 def cpu_baseline_resnet(bs, sz, steps=5):
-    """north_star: "next to the reference run on the node's own host cores (core count stated)".  The oracle's ResNet-34 step is timed
-    at 16, 32 and 64 threads (pinned to the first n allowed CPUs; 16 = the CPU share of a 1-GPU slot), `steps` timed steps after a
-    warm-up each, and `value` / `cores` are the FASTEST leg's; every leg is printed.  A leg is abandoned after its warm-up step when that
-    step is already >= 2x slower than the best leg so far (an over-subscribed host: 256 threads once measured 116 s per step)."""
+    """north_star: "next to the reference run on the node's own host cores (core count stated)".  The oracle's ResNet-34 step at the
+    thread count the parent chose (cpu_baseline_child: the cgroup quota / affinity share of this box, threads bound to cores), `steps`
+    timed steps after a warm-up.  Round 4 swept 16 / 32 / 64 threads and found the larger counts 9 - 18x slower: the boxes run under a
+    16-CPU quota (cpu_share), more threads are throttled — 16 IS this box's host share."""
     from oracle import reference_math as RM, reference_nets as RN
+    n = _cpu_threads()
     torch.manual_seed(0)
     net = RN.ImageClassificationNet(RN.resnet34(), 2, 512).train()
     params = list(net.parameters())
@@ -419,36 +488,10 @@ def cpu_baseline_resnet(bs, sz, steps=5):
         loss.backward()
         _sgd_adam_step(RM, params, state, 'sgd', 1e-2, 1e-4)
         loss.item()
-    allowed = sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else list(range(os.cpu_count() or 1))
-    legs, best_dt, best_n = {}, None, None
-    for n in (16, 32, 64):
-        if n > len(allowed) and n != 16:
-            continue
-        n = min(n, len(allowed))
-        old = _pin_process(set(allowed[:n])) if len(allowed) > n else None
-        torch.set_num_threads(n)
-        try:
-            t0 = time.time()
-            step()
-            warm = time.time() - t0
-            if best_dt is not None and warm >= 2.0 * best_dt:
-                legs[str(n)] = 'abandoned: warm-up step %.1f s vs %.2f s per step at %d threads' % (warm, best_dt, best_n)
-                continue
-            t0 = time.time()
-            for _ in range(steps):
-                step()
-            dt = (time.time() - t0) / steps
-            legs[str(n)] = round(dt * 1e3, 1)
-            if best_dt is None or dt < best_dt:
-                best_dt, best_n = dt, n
-        finally:
-            if old is not None:
-                _unpin_process(old)
-            torch.set_num_threads(_cpu_threads())
-    return dict({'value': bs / best_dt, 'unit': 'images/s', 'cores': best_n, 'kind': 'port',
-                 'sample': 'fastest of %s threads, %d timed steps each (after 1 warm-up) of the same bs=%d %dx%d ResNet-34 train step, torch-CPU oracle'
-                           % ('/'.join(legs), steps, bs, sz, sz),
-                 'ms_per_step': best_dt * 1e3, 'ms_per_step_by_threads': legs}, **host_info())
+    dt = _cpu_time(step, steps)
+    return dict({'value': bs / dt, 'unit': 'images/s', 'cores': n, 'kind': 'port',
+                 'sample': '%d timed steps (after 1 warm-up) of the same bs=%d %dx%d ResNet-34 train step, torch-CPU oracle, %d threads' % (steps, bs, sz, sz, n),
+                 'ms_per_step': dt * 1e3}, **host_info())
 
 
 def cpu_baseline_collab(bs, steps=200):
@@ -664,8 +707,7 @@ def run_config(name, device, world, rank, clock, steps, warmup, cpu):
     del wl
     torch.cuda.empty_cache()
     if cpu:
-        out['cpu_baseline'] = {'collab': lambda: cpu_baseline_collab(64), 'tabular': lambda: cpu_baseline_tabular(1024),
-                               'lm': cpu_baseline_lm, 'retinanet': cpu_baseline_retina}[name]()
+        out['cpu_baseline'] = cpu_baseline_child(name, 0, 0)
     return out
 
 
@@ -904,7 +946,15 @@ def worker(args):
             except Exception as e:                       # noqa: BLE001 — a side config must not take the headline's JSON line down
                 out['configs'][name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     if cpu:
-        out['cpu_baseline'] = cpu_baseline_resnet(args.bs, args.sz)
+        out['cpu_baseline'] = cpu_baseline_child('resnet', args.bs, args.sz)
+    if args.counters and world == 1 and rank == 0:
+        # the committed, stamp-gated figures stay the fallback; a measured pass of THIS build is reported beside them and fills the
+        # two roofline fields when the committed ones are null (any source change since the passes were committed)
+        mc = measured_counters(args)
+        out['roofline']['measured_counters'] = mc
+        if 'error' not in mc and out['roofline'].get('traffic') is None:
+            out['roofline']['traffic'], out['roofline']['mfma_busy'] = mc['traffic'], mc['mfma_busy']
+            out['roofline']['counters_source'] = mc['source']
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
@@ -923,7 +973,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true', help='skip the 1-GPU bs 8/16/32 strong-scaling proxy')
     ap.add_argument('--dry-run', action='store_true', help='CPU + gloo rehearsal of the launch / timing / JSON protocol (no HIP path)')
+    ap.add_argument('--counters', action='store_true', help='N = 1: also take the rocprofv3 --pmc passes (HBM-side bytes, MFMA busy) on this build, ~3 min')
+    ap.add_argument('--cpu-baseline-child', default=None, help='(internal) run ONE CPU baseline in this fresh process and print its JSON')
     args = ap.parse_args()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child_main(args.cpu_baseline_child, args.bs, args.sz)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))                # BEFORE any GPU call in this process
     worker(args)

@@ -70,10 +70,12 @@ class _Bucket:
     def __init__(self, params, device):
         self.params = params
         self.numel = sum(p.numel() for p in params)
-        # [gradients | one "this rank produced a gradient" flag per parameter]: the flags ride in the same collective, so
-        # every rank learns which parameters got a gradient ANYWHERE without a second message
-        self.flat = torch.zeros(self.numel + len(params), dtype=torch.float32, device=device)
-        self.flags = self.flat[self.numel:]
+        # [gradients | one "this rank produced a gradient" flag per parameter | one status word]: the flags ride in the same collective,
+        # so every rank learns which parameters got a gradient ANYWHERE without a second message; the status word of the FIRST bucket
+        # carries "a replay-overlap wait kernel timed out on this rank" to all ranks (GradSync.reduce_overlapped)
+        self.flat = torch.zeros(self.numel + len(params) + 1, dtype=torch.float32, device=device)
+        self.flags = self.flat[self.numel:self.numel + len(params)]
+        self.status = self.flat[self.numel + len(params):]
         self.views, o = [], 0
         for p in params:
             # same memory layout as the parameter (conv weights are stored channels_last): copies in and the optimizer's
@@ -244,10 +246,19 @@ class GradSync:
             return self.reduce_all(weight)
         ov.replays += 1                                   # the graph bumped the device step word: keep the host's count in step ALWAYS
         if not self.overlap_ok:
-            return self.reduce_all(weight)                # after a time-out: the round-3 behaviour (collectives behind the whole replay)
+            # after a time-out on this rank: the round-3 behaviour (collectives behind the whole replay) — the sticky error word still
+            # travels in the first bucket, so that every rank raises at this step
+            self.buckets[0].status.copy_(ov.err)
+            self.reduce_all(weight)
+            ov.stage_err(self.buckets[0].status)
+            return
         self._active, self.weight, self._next = True, float(weight), 0
         self.last_signalled = signalled
         main = torch.cuda.current_stream()
+        with torch.cuda.stream(ov.side):
+            # a time-out seen by an EARLIER step's wait kernels (the word is sticky) rides in the first bucket's status word: one step
+            # later every rank knows that some rank stepped on incomplete gradients, and all of them raise at the same step
+            self.buckets[0].status.copy_(ov.err)
         for k, b in enumerate(self.buckets):
             b.pending, b.ready, b.handle, b.averaged = 0, [True] * len(b.params), None, False
             if k < signalled:
@@ -262,7 +273,7 @@ class GradSync:
         self._next = len(self.buckets)
         main.wait_stream(ov.side)                         # (the averaged buckets are consumed on the main stream)
         self.finish()
-        ov.stage_err()                                    # async copy of the error word behind this step's work (checked with the loss)
+        ov.stage_err(self.buckets[0].status)              # async copies behind this step's work: this rank's error word, all ranks' status
 
     def _launch_filled(self, b):
         "the collective of a bucket whose flag words are already set (replay path)"
@@ -275,24 +286,34 @@ class GradSync:
 
     def raise_if_overlap_error(self, synced=False):
         """A wait kernel of the replay path ran into its time bound (the signal never came): the bucket's all-reduce then ran on
-        partially written gradients and the optimizer stepped on them — raise at once.  Called right after the per-step `loss.item()`
-        of a replayed data-parallel step (synced=True: the error word's pinned copy was enqueued before that sync, no second one) and at
-        epoch end.  The word is reset and later replays reduce after the whole replay (no wait kernels), so a caller that catches the
-        error can go on."""
+        partially written gradients and the optimizer stepped on them.  Called right after the per-step `loss.item()` of a replayed
+        data-parallel step (synced=True: the pinned copies were enqueued before that sync, no second one) and at epoch end.
+        This rank switches to collectives-after-the-replay at once (no wait kernels; the collective sequence is unchanged, so that
+        needs no agreement).  The RAISE is rank-uniform: a lone rank raises at the step itself; with several ranks the sticky error
+        word travels in the next step's first bucket (status word) and EVERY rank raises after that step's loss read — no rank is
+        left alone in a collective.  At epoch end the decision is made with one MAX all-reduce.  The words are reset on raising."""
         ov = self.overlap
         if ov is None:
             return
-        if synced and ov.host_err is not None:
-            bad = int(ov.host_err[0]) != 0
+        w = world_size()
+        if synced:
+            local, anywhere = int(ov.host_err[0]) != 0, float(ov.host_status[0]) > 0.0
         else:
-            bad = int(ov.err.item()) != 0
-        if bad:
-            ov.err.zero_()
-            if ov.host_err is not None:
-                ov.host_err.zero_()
+            local = int(ov.err.item()) != 0
+            anywhere = local
+            if w > 1:
+                t = torch.tensor([1.0 if local else 0.0], device=ov.err.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                anywhere = float(t.item()) > 0.0
+        if local:
             self.overlap_ok = False
-            raise RuntimeError('data-parallel replay: a bucket wait kernel timed out (no signal from the captured backward within '
-                               '%.0f s); the step used incomplete gradients' % (ov.timeout_us * 1e-6))
+        if anywhere or (local and w == 1):
+            ov.err.zero_()
+            ov.host_err.zero_(); ov.host_status.zero_()
+            self.buckets[0].status.zero_()
+            self.overlap_ok = False
+            raise RuntimeError('data-parallel replay: a bucket wait kernel timed out on %s (no signal from the captured backward within '
+                               '%.0f s); a step used incomplete gradients' % ('this rank' if local else 'another rank', ov.timeout_us * 1e-6))
 
     def reduce_all(self, weight=1.0):
         """After the replay of a captured forward + backward (which filled every bucket): all-reduce all buckets now, in order."""
@@ -351,9 +372,11 @@ class _ReplayOverlap:
         self.replays = 0                                                               # host mirror of the device step word
         self.timeout_us = int(float(os.environ.get('NNL_DIST_WAIT_SECONDS', 60)) * 1e6)   # wall time (device clock), not polls
         self.host_err = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.host_status = torch.zeros(1, dtype=torch.float32).pin_memory()
 
-    def stage_err(self):
+    def stage_err(self, status):
         self.host_err.copy_(self.err, non_blocking=True)
+        self.host_status.copy_(status, non_blocking=True)
 
     def _s(self):
         return torch.cuda.current_stream().cuda_stream

@@ -277,7 +277,7 @@ def test_replay_overlap_wait_times_out_loudly_and_falls_back():
     dt = time.time() - t0
     assert 0.015 < dt < 5.0, dt                             # the bound is time, not a poll count
     torch.cuda.current_stream().wait_stream(ov.side)
-    ov.stage_err()
+    ov.stage_err(gs.buckets[0].status)
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match='timed out'):
         gs.raise_if_overlap_error(synced=True)

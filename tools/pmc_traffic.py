@@ -23,14 +23,16 @@ def load(path, name):
     return tot, n
 
 
-def main(fetch_csv, write_csv, tag='r2', mfma_csv=None, stamp=None):
+def main(fetch_csv, write_csv, tag='r2', mfma_csv=None, stamp=None, write_files=True):
+    """write_files=False: only compute and return the summary dict (bench.py --counters)"""
     out = {}
     for name, path, fn in (('FETCH_SIZE', fetch_csv, tag + '_pmc_fetch_size_summary.csv'), ('WRITE_SIZE', write_csv, tag + '_pmc_write_size_summary.csv')):
         tot, n = load(path, name)
-        with open(os.path.join(ROOT, 'profiles', fn), 'w') as f:
-            f.write('Kernel_Name,Launches,%s_total_KB,%s_KB_per_launch\n' % (name, name))
-            for k in sorted(tot, key=lambda k: -tot[k]):
-                f.write('"%s",%d,%.1f,%.1f\n' % (k, n[k], tot[k], tot[k] / n[k]))
+        if write_files:
+            with open(os.path.join(ROOT, 'profiles', fn), 'w') as f:
+                f.write('Kernel_Name,Launches,%s_total_KB,%s_KB_per_launch\n' % (name, name))
+                for k in sorted(tot, key=lambda k: -tot[k]):
+                    f.write('"%s",%d,%.1f,%.1f\n' % (k, n[k], tot[k], tot[k] / n[k]))
         out[name] = (tot, n)
     (F, nF), (W, nW) = out['FETCH_SIZE'], out['WRITE_SIZE']
     is_conv = lambda k: any(t in k for t in CONV)
@@ -54,17 +56,20 @@ def main(fetch_csv, write_csv, tag='r2', mfma_csv=None, stamp=None):
         # MFMA-pipe busy fraction of the same kernels: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), summed over all launches
         B, nB = load(mfma_csv, 'SQ_VALU_MFMA_BUSY_CYCLES')
         G, _ = load(mfma_csv, 'GRBM_GUI_ACTIVE')
-        with open(os.path.join(ROOT, 'profiles', tag + '_pmc_mfma_busy.csv'), 'w') as f:
-            f.write('Kernel_Name,Launches,SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE,mfma_busy_fraction\n')
-            for k in sorted(B, key=lambda k: -B[k]):
-                if B[k] > 0:
-                    f.write('"%s",%d,%.0f,%.0f,%.4f\n' % (k, nB[k], B[k], G[k], B[k] / (G[k] / 8 * 1024)))
+        if write_files:
+            with open(os.path.join(ROOT, 'profiles', tag + '_pmc_mfma_busy.csv'), 'w') as f:
+                f.write('Kernel_Name,Launches,SQ_VALU_MFMA_BUSY_CYCLES,GRBM_GUI_ACTIVE,mfma_busy_fraction\n')
+                for k in sorted(B, key=lambda k: -B[k]):
+                    if B[k] > 0:
+                        f.write('"%s",%d,%.0f,%.0f,%.4f\n' % (k, nB[k], B[k], G[k], B[k] / (G[k] / 8 * 1024)))
         busy = sum(B[k] for k in B if main_launch(k))
         act = sum(G[k] for k in G if main_launch(k))
         js['mfma_busy'] = round(busy / (act / 8 * 1024), 4)
         js['mfma_busy_note'] = 'time-weighted over the GEMM kernels of the conv / linear launches (main_launch kernels)'
-    json.dump(js, open(os.path.join(ROOT, 'profiles', tag + '_traffic.json'), 'w'), indent=1)
-    print(json.dumps(js, indent=1))
+    if write_files:
+        json.dump(js, open(os.path.join(ROOT, 'profiles', tag + '_traffic.json'), 'w'), indent=1)
+        print(json.dumps(js, indent=1))
+    return js
 
 
 if __name__ == '__main__':
