@@ -137,6 +137,12 @@ def _learner_cls():
 def _finish(learner, world):
     if world > 1 or os.environ.get('NNL_BENCH_FORCE_DIST') == '1':
         learner.distribute(equal_shards=True)          # synthetic batches: every rank always holds a full shard
+        if world == 1:
+            # the 1-GPU rehearsal of the N > 1 legs also runs the tabular renorm sync (a no-op at world size 1 otherwise): its
+            # all-gather really goes through RCCL, and the replayed step gathers before the graph (StructuredDataNet.nnl_dp_prepare)
+            from neuralnetworklibrary_amd import dist as nnl_dist
+            from neuralnetworklibrary_amd.ops import DistComm
+            nnl_dist.enable_sync_renorm(learner.model, capacity=learner.data.bs, comm=DistComm)
     learner.model.train()
     return learner
 
@@ -973,7 +979,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-sweep', action='store_true', help='skip the 1-GPU bs 8/16/32 strong-scaling proxy')
     ap.add_argument('--dry-run', action='store_true', help='CPU + gloo rehearsal of the launch / timing / JSON protocol (no HIP path)')
-    ap.add_argument('--counters', action='store_true', help='N = 1: also take the rocprofv3 --pmc passes (HBM-side bytes, MFMA busy) on this build, ~3 min')
+    ap.add_argument('--no-counters', dest='counters', action='store_false', help='N = 1: skip the three rocprofv3 --pmc child passes (HBM-side bytes, MFMA busy of this build, ~40 s)')
     ap.add_argument('--cpu-baseline-child', default=None, help='(internal) run ONE CPU baseline in this fresh process and print its JSON')
     args = ap.parse_args()
     if args.cpu_baseline_child:

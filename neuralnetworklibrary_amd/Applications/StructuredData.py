@@ -162,12 +162,32 @@ class StructuredDataNet(nn.Module):
         cont = ops.bn_act(self.cont_bn, xcont_batch, relu=False) if self.n_cont > 0 else None
         if self.n_cat > 0:
             weights = [e.emb.weight for e in self.embeddings]
+            sync = getattr(self, 'nnl_dp', None)
+            if sync is not None and getattr(self, '_nnl_xren_ready', False):
+                sync = tuple(sync[:3]) + (self._nnl_xren,)           # all ranks' indices, gathered before the (captured) step
+                self._nnl_xren_ready = False
             combined, self._plan = ops.tab_embed_concat(xcat_batch, weights, row_masks, cont, cont_mask,
-                                                        self.embeddings[0].emb.max_norm, self._plan,
-                                                        sync=getattr(self, 'nnl_dp', None))
+                                                        self.embeddings[0].emb.max_norm, self._plan, sync=sync)
         else:
             combined = cont if cont_mask is None else cont * cont_mask
         return self.head(combined)
+
+    def nnl_dp_prepare(self, x_batch):
+        """Data-parallel replay (Learner.use_graphs under distribute()): the renorm sync's all-gather of every rank's looked-up indices
+         run EAGERLY on the step's static input, into a static buffer the captured forward reads — the collective stays
+        outside the hipGraph.  Returns True when the next forward will use the buffer."""
+        sync = getattr(self, 'nnl_dp', None)
+        if sync is None or self.n_cat == 0 or self.embeddings[0].emb.max_norm is None:
+            return False
+        xcat = x_batch[0] if isinstance(x_batch, (list, tuple)) else x_batch
+        xren = ops._global_lookup_indices(xcat.contiguous().long(), sync[:3])
+        buf = getattr(self, '_nnl_xren', None)
+        if buf is None or buf.shape != xren.shape or buf.device != xren.device:
+            self._nnl_xren = xren.clone()
+        else:
+            buf.copy_(xren)
+        self._nnl_xren_ready = True
+        return True
 
     @classmethod
     def from_dataobj(cls, data, fc_layer_sizes, emb_sizes='default', output_range=None, dropout_levels=None):

@@ -188,6 +188,8 @@ class _GraphedStep:
                 self.x = tuple(self.x)
             opt.opt.zero_grad()
             if dp:
+                for m in learner._dp_prepare_mods:    # collectives on the step's INPUTS (the tabular renorm sync's index all-gather):
+                    m.nnl_dp_prepare(self.x)          # eagerly, before the capture — the captured forward reads their static result
                 gs.begin(1.0)
                 gs.capturing = True                   # hooks fill the buckets (+ per-bucket signal kernels) but launch no collective
                 gs.prepare_overlap()                  # device words + side stream of the replay overlap (allocated OUTSIDE the capture)
@@ -219,6 +221,9 @@ class _GraphedStep:
                 dst.copy_(src, non_blocking=True)
             if not dp:
                 opt.replay_step(self.opt_capture)
+            else:
+                for m in learner._dp_prepare_mods:    # (after the new batch has reached the static inputs, before the replay)
+                    m.nnl_dp_prepare(self.x)
         self.graph.replay()
         if defer and not dp:
             # fit()'s pipelined loop: start the scalar's copy into one of two pinned slots and hand back a handle; the static loss
@@ -264,7 +269,7 @@ class Learner(object):
         self.grad_sync = None
         self._graph_warmup, self._graphs, self._graph_stateless = None, {}, None
         self._loss_host, self._loss_event = None, None
-        self._dp_weight, self._dp_equal_shards = 1.0, False
+        self._dp_weight, self._dp_equal_shards, self._dp_prepare_mods = 1.0, False, []
         # launch-bound heads (CollabFilterNet, StructuredDataNet: ~100 tiny launches per step, 2.2 - 2.4x slower eager than replayed)
         # mark themselves `nnl_default_graphs`: whole-step hipGraph replay is then ON by default on the GPU, exactly as if the notebook
         # had called learner.use_graphs() — every legality check of _graphed_step still applies per step (tensor batches, training
@@ -686,9 +691,14 @@ class Learner(object):
             # apply the capture step's masks for ever.  torch's own Dropout is graph-safe (Philox offset), the keyed path is not.
             return None
         if self.grad_sync is not None:
-            if getattr(self, '_dp_graph_ok', None) is None:      # collectives INSIDE the forward (SyncBN, renorm sync) are not captured
-                self._dp_graph_ok = not any(getattr(m, 'nnl_sync', None) is not None or getattr(m, 'nnl_dp', None) is not None
-                                            for m in self.model.modules())
+            if getattr(self, '_dp_graph_ok', None) is None:
+                # collectives INSIDE the forward / backward are not captured: SyncBN (between kernels of both passes) keeps the step
+                # eager; the tabular renorm sync only needs the step's INPUTS, so its all-gather runs before the graph
+                # (StructuredDataNet.nnl_dp_prepare) and the step replays (round 5)
+                mods = list(self.model.modules())
+                self._dp_prepare_mods = [m for m in mods if getattr(m, 'nnl_dp', None) is not None and hasattr(m, 'nnl_dp_prepare')]
+                self._dp_graph_ok = not any(getattr(m, 'nnl_sync', None) is not None
+                                            or (getattr(m, 'nnl_dp', None) is not None and not hasattr(m, 'nnl_dp_prepare')) for m in mods)
             if not self._dp_graph_ok:
                 return None
         key = (tuple((tuple(t.shape), t.dtype) for t in leaves), self.optimizer.clip is not None and bool(self.optimizer.clip))

@@ -188,7 +188,10 @@ extern "C" int nnl_embdotbias_bwd(const int64_t* x, const float* U, const float*
   NNL_CHECK_ARG(dU && dM && dbu && dbi, "embdotbias_bwd: null output");
   hipStream_t s = (hipStream_t)stream;
   const bool one_block = dM == dU + n_user * D && dbu == dM + n_item * D && dbi == dbu + n_user;
-  if (one_block && n >= 1 && n <= kScanMaxN && (n_user + n_item) * (D + 1) < (1L << 31) && NNL_ENV_INT("NNL_EMBDOT_SCAN", 1) != 0 &&
+  // (the scan costs table elements x minibatch compares: fine at MovieLens cardinalities — 81 k x 64 — but milliseconds for tables
+  // of 1e5 - 1e6 rows, ADVICE r4: above 2^27 element-sample pairs the sorted scatter below is the path)
+  if (one_block && n >= 1 && n <= kScanMaxN && (n_user + n_item) * (D + 1) < (1L << 31) && (n_user + n_item) * (D + 1) * n <= (1L << 27) &&
+      NNL_ENV_INT("NNL_EMBDOT_SCAN", 1) != 0 &&
       NNL_ENV_INT("NNL_SCATTER_ATOMIC", 0) == 0) {
     NNL_CHECK_ARG(x && U && M && dy && (z || !has_range), "embdotbias_bwd: null pointer");
     NnlProfScope prof(NNL_PROF_EMBDOT, s, (double)n * (16 + 16.0 * D + 8 + 8));

@@ -74,6 +74,7 @@ template <int NT, int kPB>     // column tiles of 16 per workgroup; partial gran
 __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
   extern __shared__ float lds[];                          // W block [Ks/4][16 NT][4], then the pair buffers [4][4 NT][64]
   __shared__ int s_pair[4][kNH];
+  __shared__ int s_done[4];                                // last step whose pair buffers the stream's first wave has consumed
   constexpr int Nsp = 16 * NT;
   constexpr int CH = 3;                                   // k groups (16 k each) per register chunk: two chunks in flight
   const int tid = threadIdx.x, lane = tid & 63;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
       *reinterpret_cast<f32x4*>(lds + ((long)kq * Nsp + col) * 4) = v;
     }
     if (tid < 4 * kNH) s_pair[tid / kNH][tid % kNH] = 0;
+    if (tid < 4) s_done[tid] = 0;
   }
   float* pairbuf = lds + (long)Ks * Nsp + (long)m * (kNH - 1) * (4 * NT * 64);      // [kNH-1][4 NT][64] of this stream
   // the (batch, unit) element of stream m this thread owns for the whole sequence: the 16 Ns elements of the stream's rows in
@@ -239,6 +241,12 @@ __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
       if (h) {
         // the other k parts: hand the sums to the stream's first wave through LDS (same lane layout on both sides)
         float* pb = pairbuf + (long)(h - 1) * (4 * NT * 64);
+        // the single pair buffer is re-written every step: not before the first wave has read step s - 1's sums (with
+        // chunk <= 64 this wave owns no phase-B element, so nothing else orders it behind that read)
+        for (int tries = 0; __hip_atomic_load(&s_done[m], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < s - 1; ++tries) {
+          if (tries > kPollLimit) { timed_out = 1; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(kBlock) void lstm_bptt2_kernel(Bptt2 p) {
             for (int hh = 1; hh < kNH; ++hh) sum += pairbuf[(long)(hh - 1) * (4 * NT * 64) + (4 * n + v) * 64 + lane];
             st_granule(pp + (v * Nsp + 16 * n) + opp, sum, tag);
           }
+        __hip_atomic_store(&s_done[m], s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);      // the pair buffers may be re-written
       }
     }
     // ---- phase B: complete dh_t of the owned element, cell backward ---------------------------------------------------

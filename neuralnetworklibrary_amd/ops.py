@@ -1200,7 +1200,14 @@ class _TabEmbedConcat(torch.autograd.Function):
         cont_mask = None if cont_mask is None else _f32c(cont_mask)
         if max_norm is not None:
             # data parallel: the in-place renorm must hit the rows looked up by ANY rank, or the replicas' tables diverge
-            xren = xcat if plan.sync is None else _global_lookup_indices(xcat, plan.sync)
+            # (Learner's replayed data-parallel step gathers them BEFORE the graph — StructuredDataNet.nnl_dp_prepare — and hands the
+            # static buffer over as a fourth element: no collective inside the captured forward)
+            if plan.sync is None:
+                xren = xcat
+            elif len(plan.sync) > 3 and plan.sync[3] is not None:
+                xren = plan.sync[3]
+            else:
+                xren = _global_lookup_indices(xcat, plan.sync[:3])
             check(lib.nnl_tab_renorm(ptr(xren), ptr(plan.ptrs), ptr(plan.card), ptr(plan.dim), ptr(plan.row_off),
                                      ptr(plan.row_table), ptr(plan.flags), xren.shape[0], plan.ncat, plan.total_rows,
                                      float(max_norm), ptr(index_error_flag(xcat.device)), stream()))
@@ -1220,7 +1227,8 @@ class _TabEmbedConcat(torch.autograd.Function):
         bs = xcat.shape[0]
         flat = torch.empty(max(plan.grad_elems, 1), dtype=torch.float32, device=dout.device)
         dcont = torch.empty(bs, n_cont, dtype=torch.float32, device=dout.device) if (n_cont and ctx.needs_input_grad[1]) else None
-        if plan.ncat and bs and 0 < plan.max_dim <= 32 and os.environ.get('NNL_TAB_SCAN', '1') != '0':
+        # (the scan costs gradient elements x minibatch compares — Rossmann: 7e4 x 1024; tables of 1e5+ rows go to the sorted scatter)
+        if plan.ncat and bs and 0 < plan.max_dim <= 32 and plan.grad_elems * bs <= (1 << 28) and os.environ.get('NNL_TAB_SCAN', '1') != '0':
             # one launch, no sort, no zero fill; a row-strided gradient (the slice of a channel-padded buffer) is read in place
             if not (dout.dtype == torch.float32 and dout.dim() == 2 and dout.stride(1) == 1 and dout.stride(0) >= dout.shape[1]):
                 dout = _f32c(dout)
@@ -1246,7 +1254,7 @@ def _global_lookup_indices(xcat, sync):
     touched embedding indices so max_norm renorm hits the same rows on every rank".  sync = (group, comm, capacity): shards
     are padded to `capacity` rows (the per-rank full batch size) so the collective has a fixed shape and needs no host
     synchronisation; padding rows are replaced by a real looked-up row (renorm is idempotent per row)."""
-    group, comm, cap = sync
+    group, comm, cap = sync[:3]
     bs, ncat = xcat.shape
     if bs > cap:
         raise _lib.NnlError(f'tab_embed_concat: local batch {bs} exceeds the data-parallel capacity {cap}')

@@ -322,3 +322,52 @@ def test_two_process_tabular_dp_with_dropout_on_reproduces_single_process():
         assert_close(two[0][2][k], two[1][2][k], 0, 1e-7, 'replicas agree: ' + k)
         assert_close(two[0][2][k], one[2][k], 2e-4, 2e-5, k)
     assert_close(np.mean([two[0][1], two[1][1]], axis=0), np.array(one[1]), 1e-4, 1e-6, 'loss curve')
+
+
+# ---- round 5: the data-parallel tabular step REPLAYS (the renorm sync's all-gather runs before the hipGraph) -------------------
+def _fit_tab_replay(rank, world, port, q, graphs):
+    import torch.distributed as dist
+    from neuralnetworklibrary_amd import dist as nd
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    set_default_device(DEV)
+    Learner.verbose = False
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    batches = [([x[0].to(DEV), x[1].to(DEV)], y.to(DEV)) for x, y in _tab_batches()] * 3            # 12 steps
+    data = _Data(nd.ShardedBatches(batches, rank, world), 8 // world)
+    learner = Learner('/tmp/nnl_tabreplay_%d_%d_%d' % (world, rank, int(graphs)), data, _tab_net(), optimizer='SGD_Mom')
+    learner.distribute()                                    # local BatchNorm (SyncBN's collectives sit inside both passes: that step stays eager)
+    learner.use_graphs(bool(graphs), warmup=2)
+    learner.model.train()
+    assert getattr(learner.model, 'nnl_dp', None) is not None          # the renorm sync is active
+    losses = [learner.train1minibatch(x, y, [5e-2, 5e-2], mom_batch=0.9) for x, y in data.train_dl]
+    learner.grad_sync.raise_if_overlap_error()
+    n_graphs = sum(g.graph is not None for g in learner._graphs.values())
+    sd = {k: v.detach().cpu().numpy() for k, v in learner.model.state_dict().items()}
+    q.put((rank, losses, sd, n_graphs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fit_tab_replay_on(rank, world, port, q):
+    _fit_tab_replay(rank, world, port, q, True)
+
+
+def _fit_tab_replay_off(rank, world, port, q):
+    _fit_tab_replay(rank, world, port, q, False)
+
+
+def test_two_process_tabular_dp_replays_with_the_renorm_sync_active():
+    """config 3 under distribute() used to fall back to the eager step because the forward contained the renorm sync's
+    all-gather.  The gather only needs the step's INPUT indices, so it now runs before the graph into a static buffer
+    (StructuredDataNet.nnl_dp_prepare) and the step is captured and replayed: same training as eager data parallelism, embedding
+    tables identical on both ranks (the renorm hit every rank's rows), ten replays."""
+    eager, replay = _run(2, _fit_tab_replay_off), _run(2, _fit_tab_replay_on)
+    assert eager[0][3] == 0 and replay[0][3] == 1 and replay[1][3] == 1
+    for k in replay[0][2]:
+        if 'running_' not in k and 'num_batches' not in k:            # (local BatchNorm: the buffers are per-replica statistics)
+            assert np.array_equal(replay[0][2][k], replay[1][2][k]), 'replicas agree bitwise: ' + k
+        for r in range(2):
+            assert_close(replay[r][2][k], eager[r][2][k], 2e-5, 2e-6, 'replayed vs eager data parallelism: ' + k)
+    for r in range(2):
+        assert_close(np.array(replay[r][1]), np.array(eager[r][1]), 1e-5, 1e-6, 'loss curve')
