@@ -157,25 +157,24 @@ int nnl_conv2d_dgrad(const float* dy, const float* wt, float* dx, const nnl_conv
  *   flip == 1: filt = wt[K,3,3,C] read as wt[.,2-r,2-s,.] (the dgrad filter: x = dy, K = C_in of the layer, wt = W^T[C,R,S,K]).
  *   ws: nnl_debug_conv_wino_workspace_bytes bytes; counters: n_counters zeroed int32 (zero again on return) or NULL (plain grid);
  *   bn_part / bn_pivot (both or neither): BatchNorm partial statistics as for nnl_conv2d_fwd, one per 64 output pairs.
- * nnl_debug_conv_plan_times: out[0..3] (FOUR doubles) = predicted launch time (us) of the direct / the 1-D Winograd / the 2-D / the spatially
- *   staged 2-D kernel (-1: shape not served) for that problem;
+ * nnl_debug_conv_plan_times: out[0..3] (FOUR doubles) = predicted launch time (us) of the direct / the 1-D Winograd / the 2-D kernel for that
+ *   problem (out[3] = -1: the spatially staged 2-D kernel of round 4 was removed in round 5);
  *   returns 1 when the dispatcher would pick the Winograd kernel, else 0. */
 /* Prepared filters.  The transformed filter of a layer depends on its weights only, so a caller that knows all its layers can
  * transform them in ONE launch per step instead of one per convolution call:
  *   nnl_conv2d_wino_preferred(g, dgrad): which kernel nnl_conv2d_fwd (dgrad = 0) / nnl_conv2d_dgrad (dgrad = 1) takes for geometry g (given
- *     the workspace of the size query): 0 direct, 1 the 1-D F(2,3) Winograd kernel, 2 the 2-D F(2x2,3x3) one, 3 the spatially staged 2-D one;
+ *     the workspace of the size query): 0 direct, 1 the 1-D F(2,3) Winograd kernel, 2 the 2-D F(2x2,3x3) one;
  *   nnl_wino_filter_multi: descriptor d transforms src [rows,3,3,ch] into dst [rows,4,3,ch]; flip = 0 with src = w[K,3,3,C]
  *     (rows = K, ch = C) gives the FORWARD filter, flip = 1 with src = W^T[C,3,3,K] (rows = C, ch = K: nnl_conv2d_weight_transpose)
  *     the DGRAD filter; block_desc[b] = descriptor served by block b, first_block = its first block, ceil(rows*3*ch / 256) blocks each;
  *   nnl_conv2d_fwd_pre / nnl_conv2d_dgrad_pre: nnl_conv2d_fwd / nnl_conv2d_dgrad with `u` = that prepared filter (NULL: exactly the
  *     plain entry points); u is used only when a Winograd kernel is taken and must then hold the layout of THAT kernel (nnl_conv2d_wino_preferred:
- *     1 -> rows * 12 * ch floats, 2 -> rows * 16 * ch floats, two_d = 1; 3 (the spatially staged 2-D kernel, csrc/wino2s.hip) ->
- *     ceil(rows / 64) * 64 * 16 * ch floats in its pre-tiled layout, two_d = 2, ceil(rows / 64) * ceil(ch / 16) blocks). */
+ *     1 -> rows * 12 * ch floats, 2 -> rows * 16 * ch floats, two_d = 1). */
 typedef struct {
   const float* src;
   float* dst;
   int32_t rows, ch, flip, first_block;
-  int32_t two_d, reserved;                   /* two_d = 1: dst [rows,16,ch] for the 2-D F(2x2,3x3) kernel, ceil(rows*ch / 256) blocks; 2: wino2s.hip's tiled layout */
+  int32_t two_d, reserved;                   /* two_d = 1: dst [rows,16,ch] for the 2-D F(2x2,3x3) kernel, ceil(rows*ch / 256) blocks */
 } nnl_wino_desc_t;
 int nnl_conv2d_wino_preferred(const nnl_conv_geom_t* g, int dgrad);
 int nnl_wino_filter_multi(const nnl_wino_desc_t* desc, const int32_t* block_desc, int64_t n_blocks, void* stream);
@@ -193,12 +192,6 @@ size_t nnl_debug_conv_wino2_workspace_bytes(int N, int H, int W, int C, int K);
 int nnl_debug_conv_wino2_fwd(const float* x, const float* filt, const float* bias, const float* add, float* y, void* ws,
                             size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
                             int H, int W, int C, int K, int relu, int flip, void* stream);
-/* the same through the spatially staged 2-D kernel (csrc/wino2s.hip: raw input rows by LDS-DMA, pre-tiled U) */
-size_t nnl_debug_conv_wino2s_workspace_bytes(int N, int H, int W, int C, int K);
-int nnl_debug_conv_wino2s_fwd(const float* x, const float* filt, const float* bias, const float* add, float* y, void* ws,
-                             size_t ws_bytes, int32_t* counters, long n_counters, float* bn_part, const float* bn_pivot, int N,
-                             int H, int W, int C, int K, int relu, int flip, void* stream);
-double nnl_debug_w2s_model(long T, long gn, long M4, int Nc, long I, long P, int ks, int S, const double* prm);   /* host-only schedule model of wino2s.hip */
 int nnl_debug_conv_plan_times(int N, int H, int W, int C, int K, double* out);
 /* dw[K,R,S,C] = sum_{n,p,q} dy[n,p,q,k] * x[n,p*stride-pad+r,q*stride-pad+s,c]; split-K partial slabs are
  * reduced in a fixed order (bitwise reproducible).  workspace: nnl_conv2d_wgrad_workspace_bytes(g). */
@@ -207,6 +200,11 @@ int nnl_conv2d_wgrad(const float* x, const float* dy, float* dw, const nnl_conv_
                      size_t workspace_bytes, void* stream);
 /* out[c] = sum_r a[r][c]  (bias gradients of conv / linear layers), two fixed-order stages (reproducible). */
 size_t nnl_colsum_workspace_bytes(int64_t rows, int64_t cols);
+/* out = src[0] + ... + src[n-1], added in that order; n in 1..8 dense fp32 tensors of numel elements, 16-byte aligned; src is a HOST
+ * array of device pointers.  Replaces autograd's chain of accumulation kernels for a parameter that several forward calls share:
+ * RetinaNet's head convolutions run on the five pyramid levels (RegressionModel / ClassificationModel.forward, retinanet.py:187-217,
+ * 260-295), so each of their 20 weight / bias gradients was four ATen add launches per step (91 per step in all). */
+int nnl_sum_tensors(const float* const* src, int n, float* out, int64_t numel, void* stream);
 int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,
                void* stream);
 /* ReLU backward gate of a conv + bias + ReLU layer (the RetinaNet head convs, retinanet.py:192-199,262-272) fused with its bias
@@ -424,8 +422,6 @@ int nnl_lstm_bwd(const float* dy, const float* dhT, const float* dcT, const floa
 /* The partition (KG x NG workgroups, k-slice Ks, column slice Ns, NT column tiles -> out5) the 2-D persistent BPTT kernel
  * (csrc/lstm_bptt2.hip) would use for this shape; returns 0 when the shape does not fit it.  Host-only. */
 int nnl_debug_lstm_bptt2_plan(int64_t B, int64_t H, int32_t* out5);
-/* The same for the 2-D persistent forward kernel (csrc/lstm_fwd2.hip): KG, NG, Ks, Us (units per column group), NT. */
-int nnl_debug_lstm_fwd2_plan(int64_t B, int64_t H, int32_t* out5);
 
 /* nn.MSELoss(reduction='mean') — `loss_func_dict['cont']` (General/Learner.py:20), the loss of the collaborative-filtering and
  * structured-data heads: *loss = mean((pred - target)^2) over n fp32 elements (one launch up to 65 536 samples, fixed-order sum);

@@ -39,8 +39,9 @@ class HipConv2d(nn.Conv2d):
         if self.dilation != (1, 1) or self.groups != 1 or self.stride[0] != self.stride[1] \
                 or self.padding[0] != self.padding[1] or self.padding_mode != 'zeros':
             raise NotImplementedError('HipConv2d: only the symmetric, dense convolutions the reference uses')
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], relu=self.fuse_relu, grad_slot=grad_slot,
-                          give_slot=give_slot)
+        # (inside ops.shared_params — the detection heads on the five pyramid levels — weight / bias are this call's aliases)
+        return ops.conv2d(x, ops.fan_param(self.weight), ops.fan_param(self.bias), self.stride[0], self.padding[0], relu=self.fuse_relu,
+                          grad_slot=grad_slot, give_slot=give_slot)
 
 
 class HipMaxPool2d(nn.MaxPool2d):

@@ -58,9 +58,6 @@ SIGNATURES = {
     'nnl_debug_conv_wino_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
     'nnl_debug_conv_wino2_workspace_bytes': (sz, [C.c_int] * 5),
     'nnl_debug_conv_wino2_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
-    'nnl_debug_conv_wino2s_workspace_bytes': (sz, [C.c_int] * 5),
-    'nnl_debug_conv_wino2s_fwd': (C.c_int, [c_p] * 6 + [sz, c_p, C.c_long, c_p, c_p] + [C.c_int] * 7 + [c_p]),
-    'nnl_debug_w2s_model': (C.c_double, [C.c_long] * 3 + [C.c_int, C.c_long, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     'nnl_debug_conv_plan_times': (C.c_int, [C.c_int] * 5 + [C.POINTER(C.c_double)]),
     'nnl_conv2d_fwd': (C.c_int, [c_p, c_p, c_p, c_p, C.POINTER(ConvGeom), C.c_int, c_p, sz, c_p, c_p, c_p, C.POINTER(i32), c_p]),
     'nnl_conv2d_weight_transpose': (C.c_int, [c_p, c_p, C.c_int, C.c_int, C.c_int, C.c_int, c_p]),
@@ -76,6 +73,7 @@ SIGNATURES = {
     'nnl_act_gate_colsum': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, C.c_int, c_p, sz, c_p]),
     'nnl_maxpool2d_fwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
     'nnl_maxpool2d_bwd': (C.c_int, [c_p, c_p, c_p, i64, i64, i64, i64, i64, i64, C.c_int, C.c_int, C.c_int, c_p]),
+    'nnl_sum_tensors': (C.c_int, [c_p, C.c_int, c_p, i64, c_p]),
     'nnl_bn_relu_maxpool_supported': (C.c_int, [i64]),
     'nnl_bn_relu_maxpool_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, i64, i64, i64,
                                           C.c_int, C.c_int, C.c_int, f32, f32, C.c_int, c_p, c_p, sz, c_p]),
@@ -106,7 +104,6 @@ SIGNATURES = {
     'nnl_lstm_fwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_lstm_bwd': (C.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, i64, i64, i64, c_p, sz, c_p, c_p]),
     'nnl_debug_lstm_bptt2_plan': (C.c_int, [i64, i64, c_p]),
-    'nnl_debug_lstm_fwd2_plan': (C.c_int, [i64, i64, c_p]),
     'nnl_embedding_rowmask_fwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, c_p, c_p]),
     'nnl_embedding_rowmask_bwd_workspace_bytes': (sz, [i64]),
     'nnl_embedding_rowmask_bwd': (C.c_int, [c_p, c_p, c_p, c_p, i64, i64, i64, i64, c_p, sz, c_p]),

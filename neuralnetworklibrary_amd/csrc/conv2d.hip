@@ -43,7 +43,7 @@ int launch_rowk(IgemmRowkParams p, hipStream_t s) {
 template <int MODE>
 int dispatch_rowk(const IgemmRowkParams& p, hipStream_t s) {
   // tuning hook (tools/bench_conv.py): NNL_IGEMM_TILE=0..3 forces 128x128 / 128x64 / 64x128 / 64x64
-  const int forced = NNL_ENV_INT("NNL_IGEMM_TILE", -1);
+  const int forced = NNL_AB_INT("NNL_IGEMM_TILE", -1);
   switch (forced) {
     case 0: return launch_rowk<128, 128, 2, 2, MODE>(p, s);
     case 1: return launch_rowk<128, 64, 2, 2, MODE>(p, s);
@@ -76,14 +76,14 @@ static bool taps_dma(int bk, const IgemmTapsParams&) {
 // profiles/r3_pf2_bs64.log): BK 16 (the 28x28 / C = 128 stage) fwd 107.0 -> 111.7 TF/s, dgrad 112.7 -> 116.7; BK 32 needs 148
 // VGPRs (three workgroups per CU instead of four) and LOSES 3-8 % on every stride-1 layer (l1 107 -> 104, l4 117 -> 109).
 static bool taps_pf2(int bk, const IgemmTapsParams&) {
-  const int m = NNL_ENV_INT("NNL_IGEMM_PF2", 1);
+  const int m = NNL_AB_INT("NNL_IGEMM_PF2", 1);
   return bk == 16 ? (m & 1) != 0 : (m & 2) != 0;
 }
 
 template <int BM, int BN, int BK = 16>
 int launch_taps(IgemmTapsParams p, hipStream_t s) {
-  p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
-  p.epi4 = NNL_ENV_INT("NNL_IGEMM_EPI4", 1);
+  p.variant = NNL_AB_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
+  p.epi4 = NNL_AB_INT("NNL_IGEMM_EPI4", 1);
   p.grid_m = (int)nnl_cdiv(p.M, BM);
   p.grid_n = (int)nnl_cdiv(p.Nc, BN);
   p.cls_tiles = p.grid_m * p.grid_n;
@@ -114,7 +114,7 @@ int launch_taps(IgemmTapsParams p, hipStream_t s) {
 template <int BK>
 int launch_taps_ktail(IgemmTapsParams p, hipStream_t s) {
   p.variant = 1;
-  p.epi4 = NNL_ENV_INT("NNL_IGEMM_EPI4", 1);
+  p.epi4 = NNL_AB_INT("NNL_IGEMM_EPI4", 1);
   p.grid_m = (int)nnl_cdiv(p.M, 64);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
   p.cls_tiles = p.grid_m * p.grid_n;
@@ -141,7 +141,7 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   const int e_bal = NNL_ENV_INT("NNL_IGEMM_BALANCE", 1);
   if (e_bal == 0 || Nc % 4 != 0) return best;
   const long gm = nnl_cdiv(M, bm), gn = nnl_cdiv(Nc, 64), T = gm * gn;
-  const int e_bk = NNL_ENV_INT("NNL_IGEMM_BK32", -1);
+  const int e_bk = NNL_AB_INT("NNL_IGEMM_BK32", -1);
   const int bk = (bm == 64 && (e_bk >= 0 ? e_bk : (T < 1200 || C >= 256 || C == 64)) && C % 32 == 0) ? 32 : 16;
   const long I = (long)ntaps * (C / bk);                               // k iterations of a whole tile
   const double c_it = (bk == 32 ? 0.60 : 0.30) * (bm / 64);            // us per k iteration per CU-resident workgroup set (measured ~113 TF/s ceiling)
@@ -155,9 +155,9 @@ BalPlan plan_balance_tile(long M, int Nc, int C, int ntaps, int bm) {
   const double plain = wave_iters(T, I) * c_it;
   best.t_us = plain;
   double best_t = plain * (e_bal == 2 ? 1.25 : 0.99);         // need a >= 1 % predicted win (2 = force, for A/B runs)
-  const int plan_extra = NNL_ENV_INT("NNL_IGEMM_PLAN_EXTRA", 2);                       // k iterations' worth of fix-up cost per sliced workgroup
-  const double plan_bw = NNL_ENV_INT("NNL_IGEMM_PLAN_BW", 16000) * 1.0e3;                  // slab traffic bandwidth, bytes per us
-  const int f_ks = NNL_ENV_INT("NNL_IGEMM_PLAN_KS", 0), f_S = NNL_ENV_INT("NNL_IGEMM_PLAN_S", 0);   // A/B hooks: force the plan's k slicing
+  const int plan_extra = NNL_AB_INT("NNL_IGEMM_PLAN_EXTRA", 2);                       // k iterations' worth of fix-up cost per sliced workgroup
+  const double plan_bw = NNL_AB_INT("NNL_IGEMM_PLAN_BW", 16000) * 1.0e3;                  // slab traffic bandwidth, bytes per us
+  const int f_ks = NNL_AB_INT("NNL_IGEMM_PLAN_KS", 0), f_S = NNL_AB_INT("NNL_IGEMM_PLAN_S", 0);   // A/B hooks: force the plan's k slicing
   if (f_ks > 0 || f_S > 0) best_t = 1e300;
   for (int ks = 1; ks <= 4; ks *= 2) {
     if (f_ks > 0 && ks != f_ks) continue;
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 }
 
 int launch_balanced(IgemmTapsParams p, const BalPlan& pl, float* ws, int* counters, hipStream_t s) {
-  p.variant = NNL_ENV_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
-  p.epi4 = NNL_ENV_INT("NNL_IGEMM_EPI4", 1);
+  p.variant = NNL_AB_INT("NNL_IGEMM_VARIANT", 1);   // 1 = pipelined LDS fragment reads (+2-3 % on BK=32)
+  p.epi4 = NNL_AB_INT("NNL_IGEMM_EPI4", 1);
   p.grid_m = (int)nnl_cdiv(p.M, pl.bm);
   p.grid_n = (int)nnl_cdiv(p.Nc, 64);
   const int T = p.grid_m * p.grid_n;
@@ -300,7 +300,7 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
     }
     return p.C >= 64 ? launch_taps_ktail<32>(p, s) : launch_taps_ktail<16>(p, s);
   }
-  const int forced = NNL_ENV_INT("NNL_IGEMM_TILE", -1);
+  const int forced = NNL_AB_INT("NNL_IGEMM_TILE", -1);
   struct Cand { int bm, bn, occ; double eff; };
   static const Cand cands[4] = {{128, 128, 4, 0.90}, {128, 64, 5, 0.90}, {64, 128, 5, 0.90}, {64, 64, 8, 1.00}};   // measured: bench_conv.py, NNL_IGEMM_TILE sweep
   int best = 0;
@@ -350,7 +350,7 @@ int dispatch_taps(const IgemmTapsParams& p_in, hipStream_t s, void* ws = nullptr
       }
       // BK=32 halves the barriers per MFMA at half the occupancy: measured (bench_conv.py --ab NNL_IGEMM_BK32=0,1) +10..20 %
       // on grids of < ~5 workgroups per CU (14x14 / 7x7 stages), -7 % on the 56x56 stage.  NNL_IGEMM_BK32=0/1 overrides.
-      const int e_bk = NNL_ENV_INT("NNL_IGEMM_BK32", -1);
+      const int e_bk = NNL_AB_INT("NNL_IGEMM_BK32", -1);
       const long blocks64 = nnl_cdiv(p.M, 64) * nnl_cdiv(p.Nc, 64) * (p.ncls > 1 ? p.ncls : 1);
       // long k loops (C >= 256) gain from BK=32 on large grids too (RetinaNet heads); so does C = 64 since the prologue / per-tap clean-ups
       // of round 3 (re-measured per layer at 64 images: l1 3x3 0.143 -> 0.138 ms; the C = 128 stage still prefers BK=16: 0.138 vs 0.147)
@@ -548,7 +548,7 @@ struct WgradPlan { int bm, bn, grid_m, grid_n, splits, k_per_split, kg; };
 WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     // != 0: square tiles only, bn must divide it (Winograd columns)
   struct Cand { int bm, bn; double cost; };                               // cost: time per FLOP relative to the 128x128 tile
   static const Cand cands[4] = {{128, 128, 1.00}, {128, 64, 1.08}, {64, 128, 1.08}, {64, 64, 1.10}};
-  const int forced = NNL_ENV_INT("NNL_WGRAD_TILE", -1);                    // tuning hook: index into cands
+  const int forced = NNL_AB_INT("NNL_WGRAD_TILE", -1);                    // tuning hook: index into cands
   const long max_splits = Kp / 256 > 0 ? Kp / 256 : 1;                    // at least 256 pixels (16 k-steps) per split
   WgradPlan pl{};
   double best_t = 1e300;
@@ -556,15 +556,15 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     /
     const Cand& c = cands[ci];
     if (square_bn_divides != 0) {
       if (c.bm != c.bn || square_bn_divides % c.bn != 0 || (c.bm == 128 && Mc < 128)) continue;
-      const int f_w = NNL_ENV_INT("NNL_WGRAD_WINO_TILE", -1);          // A/B hook: 0 = 128x128, 3 = 64x64 (when legal)
+      const int f_w = NNL_AB_INT("NNL_WGRAD_WINO_TILE", -1);          // A/B hook: 0 = 128x128, 3 = 64x64 (when legal)
       if ((f_w == 0 || f_w == 3) && ci != f_w && !(f_w == 0 && (Mc < 128 || square_bn_divides % 128 != 0))) continue;
     } else if (forced >= 0 && forced < 4 ? ci != forced : ((c.bm == 128 && Mc < 128) || (c.bn == 128 && Nc < 128))) continue;
     const long tiles = nnl_cdiv(Mc, c.bm) * nnl_cdiv(Nc, c.bn);
     const double us_per_px = (double)c.bm * c.bn * 2.0 / 441e3 * c.cost;   // one workgroup-pixel at ~113 TF/s / 256 CUs
-    const int f_sp = NNL_ENV_INT("NNL_WGRAD_SPLITS", 0);                  // A/B hook: force the split count
-    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5 || f_sp > 0 || NNL_ENV_INT("NNL_WGRAD_WGPCU10", 0) > 0); ++sp) {   // unsplit is always a candidate
+    const int f_sp = NNL_AB_INT("NNL_WGRAD_SPLITS", 0);                  // A/B hook: force the split count
+    for (long sp = 1; sp <= max_splits && (sp == 1 || tiles * sp <= 256 * 5 || f_sp > 0 || NNL_AB_INT("NNL_WGRAD_WGPCU10", 0) > 0); ++sp) {   // unsplit is always a candidate
       if (f_sp > 0 && sp != (f_sp < max_splits ? f_sp : max_splits)) continue;
-      const int f_wg = NNL_ENV_INT("NNL_WGRAD_WGPCU10", 0);                // A/B hook: workgroups per CU x 10 (e.g. 20 = two per CU)
+      const int f_wg = NNL_AB_INT("NNL_WGRAD_WGPCU10", 0);                // A/B hook: workgroups per CU x 10 (e.g. 20 = two per CU)
       if (f_wg > 0) {
         long want = (long)(f_wg * 25.6 / tiles + 0.5);
         if (want < 1) want = 1;
@@ -575,7 +575,7 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     /
       const long rs = nnl_cdiv(Kp, k1);
       if (rs != sp) continue;                                             // same plan as a smaller sp
       const long per_cu = nnl_cdiv(tiles * rs, 256);
-      const double starve = per_cu < 4 ? pow(4.0 / per_cu, NNL_ENV_INT("NNL_WGRAD_STARVE_PCT", 30) * 0.01) : 1.0;   // A/B hook: exponent x100
+      const double starve = per_cu < 4 ? pow(4.0 / per_cu, NNL_AB_INT("NNL_WGRAD_STARVE_PCT", 30) * 0.01) : 1.0;   // A/B hook: exponent x100
       const double t = (double)per_cu * k1 * us_per_px * starve + (rs > 1 ? (rs + 1.0) * Mc * Nc * 4 / 4.5e6 + 3 : 0);   // reduce: rs slab reads + one write at ~4.5 TB/s
       if (t < best_t) {
         best_t = t;
@@ -597,7 +597,7 @@ WgradPlan plan_wgrad(int Mc, int Nc, long Kp, int square_bn_divides = 0) {     /
   // with >= 16 splits (28 x 28 / 14 x 14 stages: 0.139 -> 0.136 ms and 66 -> 17 MB of slabs per launch).  With few splits the merge
   // unbalances the grid (7 x 7 stage, 7 splits: 0.142 -> 0.187 ms) and the 64x64 tile loses 1-3 %.
   pl.kg = 1;
-  const int e_kg = NNL_ENV_INT("NNL_WGRAD_KG", -1);                       // A/B hook: 1 = off, 2 / 4 = force (when legal)
+  const int e_kg = NNL_AB_INT("NNL_WGRAD_KG", -1);                       // A/B hook: 1 = off, 2 / 4 = force (when legal)
   const bool kg_tile = (pl.bm == 128 && pl.bn == 128) || (pl.bm == 64 && pl.bn == 64);
   if (kg_tile && e_kg != 1 && pl.splits >= 2) {
     int kg = (pl.bm == 128 && pl.splits >= 16) ? 4 : 1;
@@ -639,11 +639,11 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
     const long T = 128, gm = pl.grid_m, gn = pl.grid_n;
     const long fp_m = (T < gm ? T : gm) * pl.bm + nnl_cdiv(T, gm) * pl.bn;
     const long fp_n = nnl_cdiv(T, gn) * pl.bm + (T < gn ? T : gn) * pl.bn;
-    { const int e_nf = NNL_ENV_INT("NNL_WGRAD_NFAST", -1); q.n_fast = e_nf >= 0 ? e_nf : (fp_n < fp_m ? 1 : 0); }
+    { const int e_nf = NNL_AB_INT("NNL_WGRAD_NFAST", -1); q.n_fast = e_nf >= 0 ? e_nf : (fp_n < fp_m ? 1 : 0); }
   }
   const dim3 grid(pl.grid_m * pl.grid_n * pl.splits);
-  const int bk32 = NNL_ENV_INT("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
-  const int pipe = NNL_ENV_INT("NNL_WGRAD_PIPE", 1);                 // A/B hook: 1 = software-pipelined fragment reads
+  const int bk32 = NNL_AB_INT("NNL_WGRAD_BK32", 1);                  // 64x64 tile: BK=32 (16 MFMAs per barrier) measured +3 %
+  const int pipe = NNL_AB_INT("NNL_WGRAD_PIPE", 1);                 // A/B hook: 1 = software-pipelined fragment reads
   // staging LDS: 2 buffers x BK x (BM + BN) floats per wave group (dynamic: above 64 KB the kernel needs the attribute once)
   auto lds_bytes = [](int bm, int bn, int bk, int kg) { return (size_t)kg * 2 * bk * (bm + bn) * sizeof(float); };
 #define NNL_WGRAD_LAUNCH(BM_, BN_, BK_, PIPE_, KG_)                                                                              \
@@ -827,7 +827,7 @@ bool wgrad_wino2d_ok(const nnl_conv_geom_t* g) {
   const long quads = (long)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2);
   if (quads < 512 || !wgrad_v2_ok((long)g->N * g->H * g->W * g->K, (long)g->N * g->H * g->W * g->C, quads)) return false;
   if (mode == 2) return true;
-  return quads >= NNL_ENV_INT("NNL_WGRAD_WINO2D_MIN_QUADS", 1024);
+  return quads >= NNL_AB_INT("NNL_WGRAD_WINO2D_MIN_QUADS", 1024);
 }
 
 // Tile / wave-group choice of the 2-D domain, measured (tools/bench_conv.py --ab NNL_WGRAD_WINO_TILE / NNL_WGRAD_KG under NNL_WGRAD_WINO2D=2,
@@ -837,7 +837,7 @@ bool wgrad_wino2d_ok(const nnl_conv_geom_t* g) {
 WgradPlan plan_wgrad_wino2d(const nnl_conv_geom_t* g) {
   const long quads = (long)g->N * ((g->H + 1) / 2) * ((g->W + 1) / 2);
   WgradPlan pl = plan_wgrad(g->K, 16 * g->C, quads, g->C);
-  if (NNL_ENV_INT("NNL_WGRAD_WINO2D_RULE", 1) == 0 || NNL_ENV_INT("NNL_WGRAD_WINO_TILE", -1) >= 0 || NNL_ENV_INT("NNL_WGRAD_KG", -1) >= 0) return pl;
+  if (NNL_AB_INT("NNL_WGRAD_WINO2D_RULE", 1) == 0 || NNL_AB_INT("NNL_WGRAD_WINO_TILE", -1) >= 0 || NNL_AB_INT("NNL_WGRAD_KG", -1) >= 0) return pl;
   auto with_tile = [&](int bt, int splits_target) {
     WgradPlan q{};
     q.bm = q.bn = bt; q.grid_m = (int)nnl_cdiv(g->K, bt); q.grid_n = (int)nnl_cdiv(16L * g->C, bt); q.kg = 1;
@@ -852,12 +852,12 @@ WgradPlan plan_wgrad_wino2d(const nnl_conv_geom_t* g) {
   };
   const bool big = g->K >= 128 && g->C % 128 == 0;
   // big problems on wide layers (RetinaNet heads / FPN on P3: 16384 quads x 256 x 256): the 128x128 tile's operand reuse wins (0.430 -> 0.374 ms)
-  if (big && (double)quads * g->K * g->C >= NNL_ENV_INT("NNL_WGRAD_WINO2D_BIG_E6", 500) * 1e6) return pl.bm == 128 ? pl : with_tile(128, 0);
+  if (big && (double)quads * g->K * g->C >= NNL_AB_INT("NNL_WGRAD_WINO2D_BIG_E6", 500) * 1e6) return pl.bm == 128 ? pl : with_tile(128, 0);
   WgradPlan p64 = pl.bm == 64 ? pl : with_tile(64, 0);
   if (p64.splits >= 4) {                                                // four neighbouring splits -> one workgroup of four wave groups
     const long sp = nnl_cdiv(p64.splits, 4);
     const long k1 = nnl_cdiv(nnl_cdiv(quads, sp), 128L) * 128L;          // each group's share stays a multiple of 32 quads
-    if (k1 / 4 >= NNL_ENV_INT("NNL_WGRAD_WINO2D_MIN_GROUP", 700)) {      // (shorter shares: prologue / group reduction dominate — 28^2 at 32 images: -23 %)
+    if (k1 / 4 >= NNL_AB_INT("NNL_WGRAD_WINO2D_MIN_GROUP", 700)) {      // (shorter shares: prologue / group reduction dominate — 28^2 at 32 images: -23 %)
       p64.kg = 4; p64.k_per_split = (int)k1; p64.splits = (int)nnl_cdiv(quads, k1);
       return p64;
     }
@@ -1011,57 +1011,42 @@ int nnl_internal_gemm_tn(const float* a, const float* b, float* y, int Mc, int N
 // times from a model fitted to forced-schedule sweeps (wino2.hip: w2_cost) and it is taken where that prediction beats the 1-D
 // kernel's — and only where the 1-D kernel already beats the direct one: the model was not fitted on the tiny grids the direct kernel
 // keeps (profiles/r3_wino2d_*.log: -13 ... -20 % against the 1-D kernel per ResNet-34 stage at 64 images, -3 ... -9 % at 32).
-// NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal.  Mode 3 (round 4) = the spatially staged 2-D kernel (wino2s.hip: raw
-// input rows by LDS-DMA, pre-tiled U, its own event-simulated schedule model); opt-in: NNL_CONV_WINO2S=1 lets the planner take it, NNL_CONV_WINO=4 forces it.
+// NNL_CONV_WINO2=0 turns it off; NNL_CONV_WINO=3 forces it wherever legal.  (Round 4's spatially staged 2-D kernel — raw input rows by
+// LDS-DMA, 4x less traffic but issue-bound: 12.83 vs 12.59 ms per step, profiles/r4_wino2s_* — was removed in round 5.)
 static int wino_mode(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad) {
   if (!nnl_wino_ok(N, H, W, Cin, Nc, R, S, stride, pad)) return 0;
   const int e = NNL_ENV_INT("NNL_CONV_WINO", 1);
   const bool two_ok = nnl_wino2_ok(N, H, W, Cin, Nc, R, S, stride, pad);
-  const bool twos_ok = nnl_wino2s_ok(N, H, W, Cin, Nc, R, S, stride, pad);
-  if (e == 4) return twos_ok ? 3 : (two_ok ? 2 : 1);
-  if (e == 3) return two_ok ? 2 : 1;
+  if (e >= 3) return two_ok ? 2 : 1;
   if (e == 2) return 1;
   const double t_d = plan_balance((long)N * H * W, Nc, Cin, 9).t_us + 6.0;
   const double t_w = nnl_wino_plan_time_us(N, H, W, Cin, Nc) + 6.0 + 3.0 + 21.0 * Cin * Nc * 4.0 / 4.0e6;
+  const bool two_on = two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0;
   if (!(t_w < 0.97 * t_d)) {
     // small grids (round 5): the 1-D kernel loses to the direct one, but the 2-D kernel's POSITION-SPLIT plan (wino2.hip: one position per
     // workgroup, 16-way natural split) may still beat both — its cost model is calibrated on exactly these shapes (8 - 32 images)
-    if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && nnl_wino2_plan_is_pos(N, H, W, Cin, Nc) &&
-        nnl_wino2_plan_time_us(N, H, W, Cin, Nc) < 0.9 * t_d)
-      return 2;
+    if (two_on && nnl_wino2_plan_is_pos(N, H, W, Cin, Nc) && nnl_wino2_plan_time_us(N, H, W, Cin, Nc) < 0.9 * t_d) return 2;
     return 0;
   }
-  const long quad_tiles = nnl_cdiv((long)N * ((H + 1) / 2) * ((W + 1) / 2), 64L) * nnl_cdiv((long)Nc, 64L);
-  // the 2-D kernels (10 % predicted margin over the 1-D one: at 32 images they are within 5 % either way): the spatially staged one
-  // (wino2s.hip, mode 3) where ITS schedule model predicts less than the register-staged one's (wino2.hip, mode 2)
-  double t_2 = 1e300, t_3 = 1e300;
-  if (two_ok && NNL_ENV_INT("NNL_CONV_WINO2", 1) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 0)) t_2 = nnl_wino2_plan_time_us(N, H, W, Cin, Nc);
-  // OPT-IN (NNL_CONV_WINO2S=1): in the full ResNet-34 / RetinaNet steps the staged kernel measured level with the register-staged one
-  // (ResNet-34: 96.98 vs 96.0 us per launch, step 12.83 vs 12.59 ms; RetinaNet 45.6 vs 45.2 ms: profiles/r4_wino2s_step_ab.log) although it moves
-  // 1.7x fewer bytes from the L2 and 4x fewer from beyond it (profiles/r4_wino2s_pmc_l1.txt) — DESIGN.md section 3 has the analysis
-  if (twos_ok && NNL_ENV_INT("NNL_CONV_WINO2S", 0) != 0 && quad_tiles >= NNL_ENV_INT("NNL_CONV_WINO2_MIN_TILES", 0)) t_3 = nnl_wino2s_plan_time_us(N, H, W, Cin, Nc);
-  // (same-run A/B, tools/bench_wino2s.py, profiles/r4_wino2s_ab_*.log: the staged kernel wins 12 of 16 ResNet-34 shapes at 16 - 64 images and 6 of 7
-  // RetinaNet ones by 2 - 24 %, loses the rest by 2 - 7 %; the older kernel's model reads ~15 % low against this one's)
-  if (t_3 <= 1.1 * t_2 && t_3 < 0.9 * t_w) return 3;
-  if (t_2 < 0.9 * t_w) return 2;
+  // the 2-D kernel: 10 % predicted margin over the 1-D one (at 32 images they are within 5 % either way)
+  if (two_on && nnl_wino2_plan_time_us(N, H, W, Cin, Nc) < 0.9 * t_w) return 2;
   return 1;
 }
 static size_t wino_mode_workspace(int mode, int N, int H, int W, int Cin, int Nc) {
-  return mode == 3 ? nnl_wino2s_workspace_bytes(N, H, W, Cin, Nc) : mode == 2 ? nnl_wino2_workspace_bytes(N, H, W, Cin, Nc) : nnl_wino_workspace_bytes(N, H, W, Cin, Nc);
+  return mode == 2 ? nnl_wino2_workspace_bytes(N, H, W, Cin, Nc) : nnl_wino_workspace_bytes(N, H, W, Cin, Nc);
 }
 static int wino_mode_launch(int mode, const WinoProblem& q, void* ws, size_t ws_bytes, int* counters, long n_counters, hipStream_t s) {
   nnl_prof_exec_frac(mode >= 2 ? 1.0 / 2.25 : 1.0 / 1.5);                  // multiplies issued per algorithmic multiply (bench.py: roofline.executed_frac)
-  return mode == 3 ? nnl_wino2s_launch(q, ws, ws_bytes, counters, n_counters, s)
-       : mode == 2 ? nnl_wino2_launch(q, ws, ws_bytes, counters, n_counters, s) : nnl_wino_launch(q, ws, ws_bytes, counters, n_counters, s);
+  return mode == 2 ? nnl_wino2_launch(q, ws, ws_bytes, counters, n_counters, s) : nnl_wino_launch(q, ws, ws_bytes, counters, n_counters, s);
 }
 
 // debug / tuning: the planners' predicted launch times (us) for a 3x3 / stride 1 / pad 1 problem: out[0] direct, out[1] Winograd 1-D, out[2] 2-D,
-// out[3] the spatially staged 2-D kernel (-1: shape not served); out must hold FOUR doubles
+// out[3] = -1 (the slot of round 4's spatially staged kernel, removed); out must hold FOUR doubles
 extern "C" int nnl_debug_conv_plan_times(int N, int H, int W, int Cin, int Nc, double* out) {
   out[0] = plan_balance((long)N * H * W, Nc, Cin, 9).t_us;
   out[1] = nnl_wino_plan_time_us(N, H, W, Cin, Nc);
   out[2] = nnl_wino2_plan_time_us(N, H, W, Cin, Nc);
-  out[3] = nnl_wino2s_ok(N, H, W, Cin, Nc, 3, 3, 1, 1) ? nnl_wino2s_plan_time_us(N, H, W, Cin, Nc) : -1.0;
+  out[3] = -1.0;
   return wino_mode(N, H, W, Cin, Nc, 3, 3, 1, 1);
 }
 
@@ -1153,7 +1138,7 @@ extern "C" int nnl_conv2d_fwd_pre(const float* x, const float* w, const float* b
         q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
         q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
       }
-    q.tap_affine = NNL_ENV_INT("NNL_IGEMM_AFFINE", 1); q.tap_R = g->R; q.tap_S = g->S; q.tap_dh0 = 0; q.tap_dw0 = 0; q.tap_dstep = 1;
+    q.tap_affine = NNL_AB_INT("NNL_IGEMM_AFFINE", 1); q.tap_R = g->R; q.tap_S = g->S; q.tap_dh0 = 0; q.tap_dw0 = 0; q.tap_dstep = 1;
     q.bn_part = (bn_partials && bn_pivot && bn_rows) ? bn_partials : nullptr; q.bn_pivot = bn_pivot;
     return dispatch_taps(q, s, workspace, workspace_bytes, tile_counters, bn_rows);
   }
@@ -1189,7 +1174,7 @@ extern "C" int nnl_conv2d_fwd_add_up2(const float* x, const float* w, const floa
       q.tap_dh[t] = (signed char)r; q.tap_dw[t] = (signed char)ss;
       q.tap_aoff[t] = (r * g->W + ss) * g->C; q.tap_woff[t] = t * g->C;
     }
-  q.tap_affine = NNL_ENV_INT("NNL_IGEMM_AFFINE", 1); q.tap_R = g->R; q.tap_S = g->S; q.tap_dh0 = 0; q.tap_dw0 = 0; q.tap_dstep = 1;
+  q.tap_affine = NNL_AB_INT("NNL_IGEMM_AFFINE", 1); q.tap_R = g->R; q.tap_S = g->S; q.tap_dh0 = 0; q.tap_dw0 = 0; q.tap_dstep = 1;
   return dispatch_taps(q, s);            // no workspace: the plain grid (the split-tile fix-up path reads a same-shape addend only)
 }
 
@@ -1291,7 +1276,7 @@ extern "C" int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx,
       }
     };
     // all classes in ONE launch when they have the same row count (even H, W): longest classes first
-    bool merged = ncls > 1 && NNL_ENV_INT("NNL_DGRAD_MERGE", 1) != 0;
+    bool merged = ncls > 1 && NNL_AB_INT("NNL_DGRAD_MERGE", 1) != 0;
     for (int i = 1; i < ncls && merged; ++i) merged = cls[i].P == cls[0].P && cls[i].Q == cls[0].Q;
     if (merged) {
       for (int i = 1; i < ncls; ++i)                        // insertion sort by decreasing tap count (<= 4 entries)
@@ -1316,7 +1301,7 @@ extern "C" int nnl_conv2d_dgrad_pre(const float* dy, const float* wt, float* dx,
       fill(c, cls[i], 0);
       c.ntaps = cls[i].nt;
       if (st2 == 1 && cls[i].nt == g->R * g->S) {          // the full raster, r-major: (dh, dw) = (pad - r, pad - s), woff = t*K
-        c.tap_affine = NNL_ENV_INT("NNL_IGEMM_AFFINE", 1); c.tap_R = g->R; c.tap_S = g->S; c.tap_dh0 = g->pad; c.tap_dw0 = g->pad; c.tap_dstep = -1;
+        c.tap_affine = NNL_AB_INT("NNL_IGEMM_AFFINE", 1); c.tap_R = g->R; c.tap_S = g->S; c.tap_dh0 = g->pad; c.tap_dw0 = g->pad; c.tap_dstep = -1;
       }
       int st = dispatch_taps(c, s, st2 == 1 ? workspace : nullptr, workspace_bytes, tile_counters);
       if (st) return st;
@@ -1435,6 +1420,44 @@ extern "C" int nnl_act_gate_colsum(const float* dy, const float* y, float* g, fl
 extern "C" int nnl_relu_gate_colsum(const float* dy, const float* y, float* g, float* colsum, int64_t rows, int64_t cols,
                                     void* workspace, size_t workspace_bytes, void* stream) {
   return nnl_act_gate_colsum(dy, y, g, colsum, rows, cols, 1, workspace, workspace_bytes, stream);
+}
+
+// out = src[0] + src[1] + ... + src[n - 1] (in that order: bitwise reproducible), n <= 8 dense tensors of `numel` floats
+namespace {
+struct SumN { const float* src[8]; };
+__global__ __launch_bounds__(256) void sum_tensors_kernel(SumN p, int n, float* __restrict__ out, long numel) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < numel) {
+    f32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < n) v[k] = *reinterpret_cast<const f32x4*>(p.src[k] + i);
+    f32x4 acc = v[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) if (k < n) acc += v[k];
+    *reinterpret_cast<f32x4*>(out + i) = acc;
+  } else {
+    for (long j = i; j < numel; ++j) {
+      float acc = p.src[0][j];
+      for (int k = 1; k < n; ++k) acc += p.src[k][j];
+      out[j] = acc;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int nnl_sum_tensors(const float* const* src, int n, float* out, int64_t numel, void* stream) {
+  NNL_CHECK_ARG(src && out && n >= 1 && n <= 8 && numel > 0, "sum_tensors: 1 to 8 tensors of numel > 0 elements");
+  SumN p{};
+  for (int k = 0; k < n; ++k) {
+    NNL_CHECK_ARG(src[k] != nullptr && ((uintptr_t)src[k] & 15) == 0, "sum_tensors: null or unaligned source");
+    p.src[k] = src[k];
+  }
+  NNL_CHECK_ARG(((uintptr_t)out & 15) == 0, "sum_tensors: unaligned destination");
+  hipStream_t s = (hipStream_t)stream;
+  NnlProfScope prof(NNL_PROF_ELEMENTWISE, s, 4.0 * (n + 1) * numel);
+  hipLaunchKernelGGL(sum_tensors_kernel, dim3((unsigned)nnl_cdiv(nnl_cdiv(numel, 4L), 256L)), dim3(256), 0, s, p, n, out, (long)numel);
+  NNL_CHECK_LAUNCH();
+  return NNL_OK;
 }
 
 extern "C" int nnl_colsum(const float* a, float* out, int64_t rows, int64_t cols, void* workspace, size_t workspace_bytes,

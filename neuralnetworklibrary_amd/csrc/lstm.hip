@@ -35,12 +35,6 @@ hipError_t nnl_lstm_bptt2(const float* dy, const float* dhT, const float* dcT, c
                           const float* w_hh_t_pad, float* dgates_pad, float* dh0, float* dc0, long T, long B, long H, long Gp,
                           float* ws, int* err, hipStream_t s);
 
-// the 2-D partitioned persistent forward (round 4): lstm_fwd2.hip
-bool nnl_lstm_fwd2_ok(long B, long H, long Kp);
-size_t nnl_lstm_fwd2_ws_floats(long T, long B, long H, long Kp);
-hipError_t nnl_lstm_fwd2(const float* gx, const float* w_hh_pad, const float* h0, const float* c0, float* y, float* cy, float* gates,
-                         long T, long B, long H, long Kp, float* ws, int* err, hipStream_t s);
-
 namespace {
 
 constexpr int kBlock = 256;
@@ -53,8 +47,8 @@ bool persist_fwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 1) != 
 bool persist_bwd_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 2) != 0; }
 // bit 2 = the 2-D partitioned persistent BPTT (lstm_bptt2.hip; takes precedence over bit 1)
 bool bptt2_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 4) != 0; }
-// bit 3 = the 2-D partitioned persistent forward (lstm_fwd2.hip; takes precedence over bit 0)
-bool fwd2_enabled() { return (NNL_ENV_INT("NNL_LSTM_PERSIST", 5) & 8) != 0; }
+// (a 2-D partitioned persistent FORWARD — the twin of lstm_bptt2.hip, bit 3 in round 4 — only tied the first persistent forward
+// (18.3 vs 18.8 us per step at H = 1150, 14.4 vs 9.5 at H = 400: two hand-overs per step against one) and was removed in round 5)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -142,7 +136,7 @@ long ceil32(long x) { return nnl_cdiv(x, 32) * 32; }
 // (measured: 288 workgroups 10.8 ms/step of LSTM time, 216-250: 9.7 ms, 576: 11.4 ms)
 int pick_splits(long M, long N, long nk) {
   const long tiles = nnl_cdiv(M, 64) * nnl_cdiv(N, 64);
-  const long target = NNL_ENV_INT("NNL_LSTM_WG", 256);           // tuning hook: workgroup budget
+  const long target = NNL_AB_INT("NNL_LSTM_WG", 256);           // tuning hook: workgroup budget
   long s = target / tiles;
   if (s < 1) s = 1;
   if (s > nk) s = nk;
@@ -196,8 +190,6 @@ static size_t lstm_ws_floats(const Plan& p, long T, long B, long H) {
   }
   const size_t p2 = nnl_lstm_bptt2_ws_floats(T, B, H, p.Gp);     // 0 when the shape does not fit that kernel
   if (p2 > n) n = p2;
-  const size_t f2 = nnl_lstm_fwd2_ws_floats(T, B, H, p.Hp);
-  if (f2 > n) n = f2;
   return n;
 }
 
@@ -220,10 +212,6 @@ extern "C" int nnl_lstm_fwd(const float* gx, const float* w_hh_pad, const float*
   int* counters = (int*)(slabs + (long)p.sf * p.fwd_slab);
   const long BH = B * H, BG = B * 4 * H;
   NnlProfScope prof(NNL_PROF_LSTM, s, 2.0 * T * B * 4.0 * H * H);
-  if (fwd2_enabled() && err_flag != nullptr && nnl_lstm_fwd2_ok(B, H, p.Hp)) {
-    if (nnl_lstm_fwd2(gx, w_hh_pad, h0, c0, y, cy, gates, T, B, H, p.Hp, (float*)workspace, err_flag, s) == hipSuccess) return NNL_OK;
-    (void)hipGetLastError();                     // refused: nothing ran, the paths below take over
-  }
   if (persist_fwd_enabled() && err_flag != nullptr && nnl_lstm_persist_ok(B, H, p.Hp, p.Gp)) {
     // one cooperative launch for the whole sequence; if the runtime refuses it (not co-resident, LDS attribute) nothing has
     // run and the per-timestep path below takes over

@@ -338,7 +338,7 @@ Plan2 plan2(long B, long H, long Gp) {
   Plan2 best{};
   best.ok = false;
   if (B < 1 || B > kRows || H < 1 || Gp < 4 * H || Gp % 16 != 0) return best;
-  const int fkg = NNL_ENV_INT("NNL_LSTM_BPTT2_KG", 0), fng = NNL_ENV_INT("NNL_LSTM_BPTT2_NG", 0);
+  const int fkg = NNL_AB_INT("NNL_LSTM_BPTT2_KG", 0), fng = NNL_AB_INT("NNL_LSTM_BPTT2_NG", 0);
   double best_cost = 1e30;
   for (int NG = 1; NG <= 256; ++NG) {
     if (fng > 0 && NG != fng) continue;
@@ -416,13 +416,13 @@ hipError_t nnl_lstm_bptt2(const float* dy, const float* dhT, const float* dcT, c
   p.xt = p.xp + xp_granules(pl);
   p.err = err;
   p.T = (int)T; p.B = (int)B; p.H = (int)H; p.Gp = (int)Gp;
-  p.dbg = NNL_ENV_INT("NNL_LSTM_BPTT2_DBG", 0);
+  p.dbg = NNL_AB_INT("NNL_LSTM_BPTT2_DBG", 0);
   p.KG = pl.KG; p.NG = pl.NG; p.Ks = pl.Ks; p.Ns = pl.Ns; p.NWG = pl.KG * pl.NG; p.chunk = pl.chunk;
   hipError_t e = hipMemsetAsync(p.xp, 0, sizeof(u64) * (xp_granules(pl) + xt_granules(Gp)), s);     // tag 0 = nothing yet
   if (e != hipSuccess) return e;
   // partial polls of phase B in batches of 8 or 16 granules (measured: KG = 16 -> 2 x 8: 15.9 vs 16.3 us per step at H = 1150;
   // KG = 10 -> one batch of 16: 9.5 vs 10.1 at H = 400)
-  const int pb_env = NNL_ENV_INT("NNL_LSTM_BPTT2_PB", 0);
+  const int pb_env = NNL_AB_INT("NNL_LSTM_BPTT2_PB", 0);
   const int pb = pb_env == 8 || pb_env == 16 ? pb_env : (pl.KG % 8 == 0 ? 8 : 16);
 #define NNL_BPTT2_CASE(N) case N: return pb == 8 ? launch2<N, 8>(p, pl.lds, s) : launch2<N, 16>(p, pl.lds, s)
   switch (pl.NT) {

@@ -475,9 +475,9 @@ hipError_t nnl_lstm_persist_fwd(const float* gx, const float* w_hh_pad, const fl
   p.arrive = reinterpret_cast<int*>(ws + (size_t)(T + 1) * Kp * kLanes);
   p.err = err;
   p.T = (int)T; p.B = (int)B; p.H = (int)H; p.Kp = (int)Kp; p.U = sh.U; p.NWG = sh.NWG;
-  p.dbg = NNL_ENV_INT("NNL_LSTM_DBG", 0);
-  p.single = NNL_ENV_INT("NNL_LSTM_SINGLE", 1);
-  p.pd = NNL_ENV_INT("NNL_LSTM_PD", 12);
+  p.dbg = NNL_AB_INT("NNL_LSTM_DBG", 0);
+  p.single = NNL_AB_INT("NNL_LSTM_SINGLE", 1);
+  p.pd = NNL_AB_INT("NNL_LSTM_PD", 12);
   hipError_t e = hipMemsetAsync(p.arrive, 0, sizeof(int) * T, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(exchange_prologue_kernel, dim3((unsigned)nnl_cdiv(H * kLanes, 256)), dim3(256), 0, s, h0, p.xT, (int)B, (int)H,

@@ -39,6 +39,14 @@ static inline int64_t nnl_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 int nnl_env_cached(const char* name, int dflt, int* value, int* generation);
 int nnl_env_generation();          // bumped by nnl_reload_env(): caches of env-dependent plans key on it
 #define NNL_ENV_INT(name, dflt) ([]() -> int { static int v_ = 0, g_ = -1; return nnl_env_cached(name, dflt, &v_, &g_); }())
+// A/B hooks of CLOSED experiments (tile / k-block / prefetch / planner-constant sweeps, timing hacks): compiled to their
+// shipped value unless the library is built with -DNNL_AB (make AB=1: the tools/bench_*.py --ab sweeps need that build).  The shipped
+// library reads only the switches that select between TESTED algorithm families (DESIGN.md section 5 lists them).
+#ifdef NNL_AB
+#define NNL_AB_INT(name, dflt) NNL_ENV_INT(name, dflt)
+#else
+#define NNL_AB_INT(name, dflt) (dflt)
+#endif
 
 // optional per-launch profiling with HIP events on the launch stream (bench.py roofline leg)
 void nnl_prof_begin(int kind, hipStream_t s);

@@ -3,8 +3,8 @@
 // `nn.Embedding(sparse=False)` runs (CollabFiltering.py:196-204, General/Layers.py:63-76, Text.py:465-475) — adds the samples of
 // a row in sample order; atomics add them in arrival order, so gradients differed bit-wise from run to run whenever an index
 // repeated, while conv / LSTM / BN are bitwise reproducible.  Two kernels:
-//   1. rank sort: order[c][rank] = sample i, rank = #{j : key_j < key_i or (key_j == key_i and j < i)} — keys staged through LDS
-//      tiles, n^2 integer compares (n = 8192: 67 M, a few microseconds on 256 CUs), exact and stable by construction;
+//   1. rank sort: order[c][rank] = sample i, rank = #{j : key_j < key_i or (key_j == key_i and j < i)} — n^2 integer compares against
+//      wave-uniform keys (n = 8192: 67 M, a few microseconds on 256 CUs), exact and stable by construction;
 //   2. segment sum: one wave per sorted position; the wave that sits on the first sample of a row adds that row's samples — lanes
 //      across the row's elements and, for narrow rows, across sample slots that are combined by a fixed tree — and STORES the sum
 //      (rows nobody touched keep the zero of the memset).  Rows hit once or a few times are summed exactly in sample order.
@@ -14,29 +14,35 @@
 namespace nnl_det {
 
 constexpr int kSortBlock = 256;
-constexpr int kSortTile = 2048;
 constexpr long kMaxSamples = 32768;      // above this the O(n^2) ranking stops paying for itself: callers keep the atomic kernels
 
+// One wave = 64 samples i (one per lane); the block's four waves split the n keys j between them and meet in LDS.  Every lane of a wave
+// compares against the SAME key j, so the key stream is wave-uniform (scalar loads, four keys per iteration) — round 4's version gave
+// one thread a whole pass over all keys staged through an LDS tile: n / 256 workgroups (18 for the language model's 4480 tokens) of a
+// latency-bound loop, 213 us per step; this one runs n / 64 workgroups of n / 4 compares per lane.
 static __global__ __launch_bounds__(kSortBlock) void rank_sort_kernel(const int64_t* __restrict__ idx, long stride, int n,
                                                                 int* __restrict__ order) {
-  __shared__ int64_t tile[kSortTile];
-  const int c = blockIdx.y;
-  const int i = blockIdx.x * kSortBlock + threadIdx.x;
+  __shared__ int part[4][64];
+  const int c = blockIdx.y, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int i = blockIdx.x * 64 + lane;
   const int64_t ki = i < n ? idx[(long)i * stride + c] : 0;
+  const int per = (n + 3) / 4, j0 = w * per, j1 = min(j0 + per, n);
+  const int64_t* kp = idx + c;
   int rank = 0;
-  for (int t0 = 0; t0 < n; t0 += kSortTile) {
-    const int tn = min(kSortTile, n - t0);
-    __syncthreads();
-    for (int j = threadIdx.x; j < tn; j += kSortBlock) tile[j] = idx[(long)(t0 + j) * stride + c];
-    __syncthreads();
-    if (i < n) {
-      // keys before sample i in the tile count on "<=", keys after it on "<": ties keep sample order
-      const int split = min(max(i - t0, 0), tn);
-      for (int j = 0; j < split; ++j) rank += tile[j] <= ki;
-      for (int j = split; j < tn; ++j) rank += tile[j] < ki;
-    }
+  int j = j0;
+  // rank = #{j : key_j < key_i or (key_j == key_i and j < i)}: ties keep sample order (stable)
+  for (; j + 3 < j1; j += 4) {
+    const int64_t k0 = kp[(long)j * stride], k1 = kp[(long)(j + 1) * stride], k2 = kp[(long)(j + 2) * stride], k3 = kp[(long)(j + 3) * stride];
+    rank += (k0 < ki || (k0 == ki && j < i)) + (k1 < ki || (k1 == ki && j + 1 < i)) + (k2 < ki || (k2 == ki && j + 2 < i)) + (k3 < ki || (k3 == ki && j + 3 < i));
   }
-  if (i < n) order[(long)c * n + rank] = i;
+  for (; j < j1; ++j) {
+    const int64_t kj = kp[(long)j * stride];
+    rank += kj < ki || (kj == ki && j < i);
+  }
+  part[w][lane] = rank;
+  __syncthreads();
+  if (w == 0 && i < n) order[(long)c * n + part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]] = i;
 }
 
 struct SegSumParams {
@@ -112,7 +118,7 @@ static __global__ __launch_bounds__(256) void segsum4_kernel(SegSumParams4 ps) {
 static inline size_t order_bytes(long n, int ncols) { return (size_t)n * ncols * sizeof(int); }
 
 static inline int sort_rows(const int64_t* idx, long stride, long n, int ncols, int* order, hipStream_t s) {
-  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)nnl_cdiv(n, kSortBlock), ncols), dim3(kSortBlock), 0, s, idx, stride, (int)n, order);
+  hipLaunchKernelGGL(rank_sort_kernel, dim3((unsigned)nnl_cdiv(n, 64L), ncols), dim3(kSortBlock), 0, s, idx, stride, (int)n, order);
   NNL_CHECK_LAUNCH();
   return NNL_OK;
 }

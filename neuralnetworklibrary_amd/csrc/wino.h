@@ -26,12 +26,3 @@ bool nnl_wino2_plan_is_pos(int N, int H, int W, int Cin, int Nc);      // the pl
 size_t nnl_wino2_workspace_bytes(int N, int H, int W, int Cin, int Nc);
 int nnl_wino2_bn_rows(int N, int H, int W);
 int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_counters, long n_counters, hipStream_t s);
-
-// the spatially staged 2-D variant (wino2s.hip): raw input rows staged by LDS-DMA, U pre-tiled per 64-channel tile / position row / 8-channel
-// block (nnl_wino2s_u_floats floats; u_pre must be in THAT layout)
-bool nnl_wino2s_ok(int N, int H, int W, int Cin, int Nc, int R, int S, int stride, int pad);
-double nnl_wino2s_plan_time_us(int N, int H, int W, int Cin, int Nc);
-size_t nnl_wino2s_u_floats(int Cin, int Nc);
-size_t nnl_wino2s_workspace_bytes(int N, int H, int W, int Cin, int Nc);
-int nnl_wino2s_bn_rows(int N, int H, int W);
-int nnl_wino2s_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_counters, long n_counters, hipStream_t s);

@@ -64,10 +64,6 @@ __global__ void wino_filter_multi_kernel(const nnl_wino_desc_t* __restrict__ des
   const nnl_wino_desc_t d = desc[block_desc[blockIdx.x]];
   const long i = ((long)blockIdx.x - d.first_block) * 256 + threadIdx.x;
   const long C = d.ch;
-  if (d.two_d == 2) {                                // the pre-tiled U of the spatially staged 2-D kernel (wino2s.hip): one block per (64 rows, 16 channels)
-    wino2s_filter_block(d.src, d.dst, (long)blockIdx.x - d.first_block, threadIdx.x, d.rows, (int)C, d.flip);
-    return;
-  }
   if (d.two_d) {                                     // U [rows][16][ch] of the 2-D kernel: one (row, channel) item per thread
     if (i < (long)d.rows * C) wino2_filter_item(d.src + (i / C) * 9 * C + i % C, d.dst + (i / C) * 16 * C + i % C, C, d.flip);
     return;
@@ -416,7 +412,7 @@ struct WPlan {
 WPlan wino_plan(long M2, int Nc, int C) {
   WPlan best{};
   const long gm = nnl_cdiv(M2, 64), gn = nnl_cdiv(Nc, 64), T = gm * gn;
-  const int e_bk = NNL_ENV_INT("NNL_WINO_BK", 0);
+  const int e_bk = NNL_AB_INT("NNL_WINO_BK", 0);
   // BK 32 where the per-tap channel loop is short (C = 64: 134.5 -> 137.5 TF/s) or the grid small (7x7 stage: 116 -> 125); BK 16
   // otherwise (28x28 / 14x14 stages: 144 / 151 against 141 / 147) — tools/bench_conv.py --ab NNL_WINO_BK=16,32
   best.bk = (e_bk == 16 || e_bk == 32) ? e_bk : ((C % 32 == 0 && (C == 64 || T < 300)) ? 32 : 16);
@@ -513,7 +509,7 @@ int nnl_wino_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_c
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.W2 = (q.W + 1) / 2; p.M2 = (int)M2; p.Nc = q.Nc; p.relu = q.relu;
   p.grid_m = (int)nnl_cdiv(M2, 64L); p.grid_n = (int)nnl_cdiv(q.Nc, 64);
   p.bn_part = q.bn_part; p.bn_pivot = q.bn_pivot;
-  p.epi4 = NNL_ENV_INT("NNL_WINO_EPI4", 1);
+  p.epi4 = NNL_AB_INT("NNL_WINO_EPI4", 1);
   const long T = (long)p.grid_m * p.grid_n;
   WPlan pl = wino_plan(M2, q.Nc, q.Cin);
   if (pl.on && (tile_counters == nullptr || T > n_counters || ws_bytes < (u_floats + pl.main_floats + pl.tail_floats) * sizeof(float) ||

@@ -558,7 +558,7 @@ double w2_pos_cost(long T, long M4, int Nc, int C, int cs) {
 // the slab round trips at a fitted 11.7 TB/s and 10 us of launch + filter pre-pass.
 double w2_cost(long T, long gn, long M4, int Nc, long I, int bk, int ks, int S, W2Plan* out) {
   const double a = bk == 32 ? 0.363 : 0.226, b = bk == 32 ? 0.490 : 0.243, tfix = bk == 32 ? 12.3 : 15.0;
-  const long occ = (bk == 16 && NNL_ENV_INT("NNL_WINO2_OCC", 4) != 3) ? 4 : 3;
+  const long occ = (bk == 16 && NNL_AB_INT("NNL_WINO2_OCC", 4) != 3) ? 4 : 3;
   long n_main = ((T * ks / kCUs) * kCUs / ks / gn) * gn;
   if (n_main > T) n_main = T;
   const long tail = T - n_main;
@@ -581,7 +581,7 @@ double w2_cost(long T, long gn, long M4, int Nc, long I, int bk, int ks, int S, 
 W2Plan wino2_plan(long M4, int Nc, int C) {
   W2Plan best{};
   const long gm = nnl_cdiv(M4, 64), gn = nnl_cdiv(Nc, 64), T = gm * gn;
-  const int e_bk = NNL_ENV_INT("NNL_WINO2_BK", 0);
+  const int e_bk = NNL_AB_INT("NNL_WINO2_BK", 0);
   const int f_ks = NNL_ENV_INT("NNL_WINO_PLAN_KS", 0), f_S = NNL_ENV_INT("NNL_WINO_PLAN_S", 0);
   const bool balance = NNL_ENV_INT("NNL_WINO_BALANCE", 1) != 0;
   double best_t = 1e300;
@@ -609,7 +609,7 @@ W2Plan wino2_plan(long M4, int Nc, int C) {
   }
   // the position-split instantiation (small grids): NNL_WINO2_POS = -1 (default) by predicted time, 0 never, n > 0 forces n channel slices
   const int e_pos = NNL_ENV_INT("NNL_WINO2_POS", -1);
-  if (e_pos != 0 && C % 32 == 0 && (e_bk == 0 || e_bk == 32)) {
+  if (e_pos != 0 && (balance || e_pos > 0) && C % 32 == 0 && (e_bk == 0 || e_bk == 32)) {      // (a split schedule: off with NNL_WINO_BALANCE=0)
     const int csteps = C / 32;
     double pt = 1e300; int pcs = 0;
     for (int cs = 1; cs <= 8; cs *= 2) {
@@ -668,8 +668,8 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
   {
     const int e_ch = NNL_ENV_INT("NNL_WINO2_CHUNK", 0);                  // 0: the whole C (position-major order); else a multiple of 32 dividing C
     p.ch = (e_ch > 0 && e_ch % 32 == 0 && q.Cin % e_ch == 0) ? e_ch : q.Cin;
-    p.prio = NNL_ENV_INT("NNL_WINO2_PRIO", 0);
-    p.fold_skip = NNL_ENV_INT("NNL_WINO2_FOLD_SKIP", 1);
+    p.prio = NNL_AB_INT("NNL_WINO2_PRIO", 0);
+    p.fold_skip = NNL_AB_INT("NNL_WINO2_FOLD_SKIP", 1);
   }
   p.H = q.H; p.W = q.W; p.C = q.Cin; p.H2 = (q.H + 1) / 2; p.W2 = (q.W + 1) / 2; p.M4 = (int)M4; p.Nc = q.Nc; p.relu = q.relu;
   {
@@ -706,7 +706,7 @@ int nnl_wino2_launch(const WinoProblem& q, void* ws, size_t ws_bytes, int* tile_
     grid = (unsigned)(pl.n_main_tiles * pl.main_ks + (T - pl.n_main_tiles) * pl.tail_slices);
   }
   if (pl.bk == 32) hipLaunchKernelGGL((wino2_kernel<32, 3>), dim3(grid), dim3(256), 0, s, p);
-  else if (NNL_ENV_INT("NNL_WINO2_OCC", 4) == 3) hipLaunchKernelGGL((wino2_kernel<16, 3>), dim3(grid), dim3(256), 0, s, p);
+  else if (NNL_AB_INT("NNL_WINO2_OCC", 4) == 3) hipLaunchKernelGGL((wino2_kernel<16, 3>), dim3(grid), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wino2_kernel<16, 4>), dim3(grid), dim3(256), 0, s, p);
   NNL_CHECK_LAUNCH();
   return NNL_OK;

@@ -17,6 +17,13 @@ __all__ = ['mse_loss', 'scaled_sigmoid', 'embdotbias', 'index_error_flag', 'rais
 _ERR_FLAGS = {}
 
 
+def _ab(name, default):
+    """A/B hook of a CLOSED experiment: the shipped package runs its default; the variable is read only in an
+    A/B session (NNL_AB=1 in the environment, with the `make AB=1` library for the C-side hooks)."""
+    return os.environ.get(name, default) if os.environ.get('NNL_AB') == '1' else default
+
+
+
 def _flags(device):
     key = (device.type, device.index)
     if key not in _ERR_FLAGS:
@@ -203,14 +210,14 @@ _WT_ACTIVE = {}       # weight data_ptr -> W^T tensor [C,R,S,K]; valid ONLY betw
 # `prepare_forward(model)` (Learner, before the forward of a training step) and `prepare_backward(model)` transform the filters of all
 # layers that took the Winograd kernel at their LAST call (`_WINO_PREF`) in one launch each; the convolutions pick them up by weight
 # address.  The window closes in finish_backward() (Learner: in a `finally`), before the optimizer touches the weights.
-_WINO_U_FWD, _WINO_U_BWD = {}, {}     # weight data_ptr -> U [K,4,3,C] (forward) / U' [C,4,3,K] (dgrad)
-_WINO_PREF = {}                       # weight data_ptr -> [forward took the Winograd kernel, dgrad did] at the last call
+_WINO_U_FWD, _WINO_U_BWD = {}, {}     # (weight data_ptr, kernel mode) -> U [K,4|16,3|1,C] (forward) / U' [C,...,K] (dgrad) in that kernel's layout
+_WINO_PREF = {}                       # weight data_ptr -> [modes the forward calls took, modes the dgrad calls took] (sets; 1 = 1-D, 2 = 2-D kernel):
+                                      # a weight shared between geometries (RetinaNet's heads: five pyramid levels) may need BOTH layouts
 
 
 class _WinoBatch:
     """persistent U buffers + device descriptor tables for nnl_wino_filter_multi: items = [(key_ptr, src tensor [rows,3,3,ch], flip, mode)],
-    mode as nnl_conv2d_wino_preferred: 1 -> U [rows,12,ch] (1-D kernel), 2 -> U [rows,16,ch] (2-D kernel), 3 -> the pre-tiled U of the spatially
-    staged 2-D kernel (rows padded to 64)"""
+    mode as nnl_conv2d_wino_preferred: 1 -> U [rows,12,ch] (1-D kernel), 2 -> U [rows,16,ch] (2-D kernel)"""
 
     def __init__(self, items):
         import numpy as np
@@ -226,11 +233,11 @@ class _WinoBatch:
             n = _wino_u_numel(rows, ch, mode)
             u = self.flat[off:off + n]
             off += n
-            nb = {3: -(-rows // 64) * -(-ch // 16), 2: (rows * ch + 255) // 256}.get(mode, (rows * 3 * ch + 255) // 256)
-            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first, {3: 2, 2: 1}.get(mode, 0), 0)
+            nb = (rows * ch + 255) // 256 if mode == 2 else (rows * 3 * ch + 255) // 256
+            desc[i] = (t.data_ptr(), u.data_ptr(), rows, ch, flip, first, 1 if mode == 2 else 0, 0)
             block_desc += [i] * nb
             first += nb
-            self.views[k] = u
+            self.views[(k, mode)] = u
         self.n_blocks = first
         self.desc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
         self.block_desc = torch.tensor(block_desc, dtype=torch.int32, device=dev)
@@ -241,7 +248,7 @@ class _WinoBatch:
 
 def _wino_u_numel(rows, ch, mode):
     "floats of the transformed filter in the layout of kernel `mode` (include/nnl.h: nnl_conv2d_wino_preferred)"
-    return {3: -(-rows // 64) * 64 * 16 * ch, 2: rows * 16 * ch}.get(mode, rows * 12 * ch)
+    return rows * 16 * ch if mode == 2 else rows * 12 * ch
 
 
 def _wino_batch_key(items):
@@ -279,10 +286,11 @@ def prepare_forward(model):
     items = []
     for m in _conv_mods(model):
         w = m.weight
-        mode = _WINO_PREF.get(w.data_ptr(), (0, 0))[0]
-        if (mode and w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.dtype == torch.float32
+        modes = _WINO_PREF.get(w.data_ptr(), ((), ()))[0]
+        if (modes and w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.dtype == torch.float32
                 and w.is_contiguous(memory_format=torch.channels_last)):
-            items.append((w.data_ptr(), w.permute(0, 2, 3, 1), 0, mode))    # KRSC view of the same memory
+            for mode in sorted(modes):
+                items.append((w.data_ptr(), w.permute(0, 2, 3, 1), 0, mode))    # KRSC view of the same memory
     _run_wino_batch(model, '_nnl_wino_fwd_batch', items, _WINO_U_FWD)
 
 
@@ -338,8 +346,8 @@ def prepare_backward(model):
     # the dgrad Winograd filters U' [C,4,3,K] of the layers whose last dgrad took the Winograd kernel, from the transposes above
     _WINO_U_BWD.clear()
     if os.environ.get('NNL_WINO_PREPARE', '1') != '0':
-        items = [(w.data_ptr(), batch.views[w.data_ptr()], 1, _WINO_PREF[w.data_ptr()][1]) for w in ws
-                 if w.shape[2] == 3 and w.shape[3] == 3 and _WINO_PREF.get(w.data_ptr(), (0, 0))[1]]
+        items = [(w.data_ptr(), batch.views[w.data_ptr()], 1, mode) for w in ws if w.shape[2] == 3 and w.shape[3] == 3
+                 for mode in sorted(_WINO_PREF.get(w.data_ptr(), ((), ()))[1])]
         _run_wino_batch(model, '_nnl_wino_bwd_batch', items, _WINO_U_BWD)
 
 
@@ -360,10 +368,10 @@ def _wino_pref(key_ptr, which, g):
     per weight for the next step's batch (a weight shared between geometries keeps the mode of its LAST call; calls whose mode
     differs transform their own filter: the prepared buffer is only handed over when its size is that of the mode's layout)"""
     pref = int(lib.nnl_conv2d_wino_preferred(g, which)) if (g.R == 3 and g.S == 3 and g.stride == 1) else 0
-    if pref or key_ptr in _WINO_PREF:
+    if pref:
         if len(_WINO_PREF) > 8192:
             _WINO_PREF.clear()
-        _WINO_PREF.setdefault(key_ptr, [0, 0])[which] = pref
+        _WINO_PREF.setdefault(key_ptr, [set(), set()])[which].add(pref)
     return pref
 
 
@@ -404,7 +412,7 @@ def _tile_counters(device):
     device: every op of this package runs on torch's current stream, one conv at a time (a captured step replays on that same
     stream).  Created on first use outside stream capture (eager warm-up steps precede every capture)."""
     import os
-    if os.environ.get('NNL_IGEMM_FIXUP', '1') == '0':
+    if _ab('NNL_IGEMM_FIXUP', '1') == '0':
         return None
     t = _TILE_COUNTERS.get(device.index)
     if t is None:
@@ -446,7 +454,7 @@ class GradSlot:
 class _Side:
     stream = None
     used = False
-    enabled = os.environ.get('NNL_WGRAD_SIDE_STREAM', '0') == '1'      # OPT-IN: measured +0.7 % on the LM step (profiles/r4_lm_side_stream_ab.log)
+    enabled = _ab('NNL_WGRAD_SIDE_STREAM', '0') == '1'      # OPT-IN: measured +0.7 % on the LM step (profiles/r4_lm_side_stream_ab.log)
     pending_param = None          # set by linear(..., wgrad_side=True) for the _Conv2d.forward that follows
 
 
@@ -491,6 +499,72 @@ def side_join():
         _Side.used = False
 
 
+# ---- parameters shared by several forward calls of one step (RetinaNet's heads on the five pyramid levels) ----------------------------
+# Autograd sums the per-call gradients of such a parameter with a chain of accumulation kernels (4 adds per tensor and step; 91 ATen
+# launches per RetinaNet step, 0.54 ms: profiles/r4_retinanet_kernel_stats.csv).  `shared_params(modules, n)` hands every parameter
+# of `modules` out as n ALIASES (same storage) produced by one autograd node whose backward adds the n gradients in call order with ONE
+# launch (nnl_sum_tensors); HipConv2d.forward takes the next alias of its weight / bias (`fan_param`).  The same sum as autograd's
+# accumulation up to the order of the additions (call order here, backward order there); bitwise reproducible run to run.
+_FAN = {}
+
+
+class _FanOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, n):
+        ctx.n = n
+        return tuple(p.detach().view(p.shape) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        have = [g for g in grads if g is not None]
+        if not have:
+            return None, None
+        if len(have) == 1:
+            return have[0], None
+        g0 = have[0]
+        dense = all(g.is_cuda and g.dtype == torch.float32 and g.shape == g0.shape and g.stride() == g0.stride() and g.data_ptr() % 16 == 0
+                    and (g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))) for g in have)
+        if not dense or len(have) > 8:
+            out = have[0]
+            for g in have[1:]:
+                out = out + g
+            return out, None
+        out = torch.empty_like(g0)                       # (preserves the dense layout of the operands)
+        arr = (ctypes.c_void_p * len(have))(*[g.data_ptr() for g in have])
+        check(lib.nnl_sum_tensors(arr, len(have), ptr(out), g0.numel(), stream()))
+        return out, None
+
+
+class shared_params:
+    """with shared_params([module, ...], n_calls): ... the n_calls forward calls of the modules ...   (training with autograd only:
+    outside it — evaluation, no_grad — the modules use their parameters directly)"""
+
+    def __init__(self, modules, n):
+        self.modules, self.n, self.keys = modules, int(n), []
+
+    def __enter__(self):
+        if self.n > 1 and torch.is_grad_enabled():
+            for m in self.modules:
+                for p in m.parameters():
+                    if p.requires_grad and p.is_cuda and id(p) not in _FAN:
+                        _FAN[id(p)] = list(_FanOut.apply(p, self.n))
+                        self.keys.append(id(p))
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.keys:
+            _FAN.pop(k, None)
+        return False
+
+
+def fan_param(p):
+    "the next alias of a parameter inside `shared_params`, else the parameter itself"
+    if p is None or not _FAN:
+        return p
+    lst = _FAN.get(id(p))
+    return lst.pop(0) if lst else p
+
+
 class _Conv2d(torch.autograd.Function):
     """nn.Conv2d forward/backward (reference Applications/VisionModels/retinanet.py:26-28,66-71,106-124,169-185,
     241-257,304,345) on the fp32-MFMA implicit-GEMM kernels; optional fused bias + ReLU epilogue."""
@@ -518,7 +592,7 @@ class _Conv2d(torch.autograd.Function):
         if bn_pivot is not None:                                  # BatchNorm statistics from the conv epilogue (include/nnl.h)
             part = torch.empty(((N * g.P * g.Q + 63) // 64) * K * 2, dtype=torch.float32, device=x.device)
         wmode = _wino_pref(wn.data_ptr(), 0, g)
-        u = _WINO_U_FWD.get(wn.data_ptr()) if wmode else None   # the filter prepared for this step, if any — in THIS call's layout
+        u = _WINO_U_FWD.get((wn.data_ptr(), wmode)) if wmode else None   # the filter prepared for this step, if any — in THIS call's layout
         if u is not None and u.numel() != _wino_u_numel(K, C, wmode):
             u = None
         check(lib.nnl_conv2d_fwd_pre(ptr(xn), ptr(wn), ptr(b), ptr(y), g, int(relu), ptr(ws), wsb, ptr(_tile_counters(x.device) if wsb else None),
@@ -551,7 +625,7 @@ class _Conv2d(torch.autograd.Function):
             return _Conv2d._backward_padded(ctx, dyn, wn, xn, g, K)
         dyn = to_nhwc(dy.float())
         db_gated = None
-        if ctx.relu == 1 and os.environ.get('NNL_RELU_GATE', '1') == '0':
+        if ctx.relu == 1 and _ab('NNL_RELU_GATE', '1') == '0':
             dyn = dyn * (y > 0)
         elif ctx.relu:
             # ReLU / sigmoid gate (+ the bias gradient of the gated dy) in one pass
@@ -572,7 +646,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_w, dyn_w, wn_w = g, dyn, wn                   # (the weight gradient keeps the unpadded operands)
             ktail = g.R == 1 and g.S == 1 and g.K % 4 == 0 and os.environ.get('NNL_IGEMM_KTAIL', '1') != '0'     # the tap kernel masks the k tail itself
-            if g.K % 16 != 0 and g.K >= 32 and not ktail and os.environ.get('NNL_DGRAD_PAD16', '1') != '0':
+            if g.K % 16 != 0 and g.K >= 32 and not ktail and _ab('NNL_DGRAD_PAD16', '1') != '0':
                 # dgrad reduces over K: the tap-table kernel needs K % 16 == 0 (RetinaNet's 36- / 180-channel output convs would
                 # fall back to the first-generation kernel, ~2.5x slower); zero channels cost one copy of dy
                 padk = 16 - g.K % 16
@@ -593,7 +667,7 @@ class _Conv2d(torch.autograd.Function):
             fuse = shortcut is not None and g.K % 16 == 0 and shortcut.numel() == dxn.numel() \
                 and (g.stride == 1 or (g.stride == 2 and g.R == 3 and g.S == 3 and g.pad == 1))
             wmode = _wino_pref(wn.data_ptr(), 1, g)
-            u = _WINO_U_BWD.get(wn.data_ptr()) if (wmode and g.K == K) else None
+            u = _WINO_U_BWD.get((wn.data_ptr(), wmode)) if (wmode and g.K == K) else None
             if u is not None and u.numel() != _wino_u_numel(g.C, g.K, wmode):
                 u = None
             check(lib.nnl_conv2d_dgrad_pre(ptr(dyn), ptr(wt), ptr(dxn), g, ptr(shortcut) if fuse else None, ptr(dws), wsb,
@@ -800,7 +874,7 @@ def linear(x, weight, bias=None, relu=False, wgrad_side=False):
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     if (not relu and weight.shape[0] <= 4 and x2.is_cuda and x2.shape[0] > 0
-            and os.environ.get('NNL_LINEAR_SMALL', '1') != '0'):
+            and _ab('NNL_LINEAR_SMALL', '1') != '0'):
         return _LinearSmall.apply(x2, weight, bias).reshape(*lead, weight.shape[0])
     _Side.pending_param = weight if (wgrad_side and weight.requires_grad) else None
     y = _Conv2d.apply(x2[:, :, None, None], weight[:, :, None, None], bias, 1, 0, int(relu), None, None)[0]

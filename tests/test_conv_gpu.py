@@ -355,110 +355,6 @@ def test_prepared_winograd_filters_match_per_call_transform(mode, monkeypatch):
     monkeypatch.delenv('NNL_CONV_WINO'); lib.nnl_reload_env()
 
 
-@pytest.mark.parametrize('case', [(2, 64, 12, 10, 64, None), (3, 32, 9, 7, 48, None), (4, 128, 14, 14, 128, (2, 4)), (1, 16, 2, 70, 16, None),
-                                  (2, 64, 17, 33, 96, (1, 3)), (5, 512, 7, 7, 512, (4, 8)), (70, 64, 14, 14, 64, None), (3, 16, 11, 14, 80, None)], ids=str)
-def test_winograd_2d_staged_debug_entry(case, monkeypatch):
-    """The spatially staged 2-D F(2x2, 3x3) kernel (csrc/wino2s.hip: raw input rows by LDS-DMA, pre-tiled U, 16-slot MFMA schedule) through
-    its debug entry nnl_debug_conv_wino2s_fwd: forward with bias / addend / ReLU / BatchNorm partial sums and the flipped dgrad filter, odd
-    heights and widths, one-row images (H2 = 1), the 7x7 stage (W2 = 4: 17 row segments per tile), tiles that straddle images, ragged
-    channel counts (K not a multiple of 64), plain grid and forced k-slicing (in-kernel slab fix-up), against torch CPU fp32."""
-    from neuralnetworklibrary_amd._lib import lib, ptr, stream, check
-    N, C, H, W, K, forced = case
-    if forced:
-        monkeypatch.setenv('NNL_WINO_PLAN_KS', str(forced[0])); monkeypatch.setenv('NNL_WINO_PLAN_S', str(forced[1]))
-    lib.nnl_reload_env()
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(N, H, W, C, generator=g)
-    w = torch.randn(K, 3, 3, C, generator=g) / (C * 9) ** 0.5
-    b = torch.randn(K, generator=g)
-    add = torch.randn(N, H, W, K, generator=g)
-    piv = torch.randn(K, generator=g) * 0.1
-    dy = torch.randn(N, H, W, K, generator=g)
-    counters = torch.zeros(4096, dtype=torch.int32, device=DEV)
-    wsb = max(lib.nnl_debug_conv_wino2s_workspace_bytes(N, H, W, C, K), lib.nnl_debug_conv_wino2s_workspace_bytes(N, H, W, K, C))
-    ws = torch.empty(wsb // 4 + 4, device=DEV)
-    rows = (N * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64
-    part = torch.zeros(rows, K, 2, device=DEV)
-    xd, wd, bd, addd, pivd = x.to(DEV), w.to(DEV), b.to(DEV), add.to(DEV), piv.to(DEV)
-    y = torch.empty(N, H, W, K, device=DEV)
-
-    def run(xin, filt, bias, addt, out, cc, kk, relu, flip, bn):
-        check(lib.nnl_debug_conv_wino2s_fwd(ptr(xin), ptr(filt), ptr(bias), ptr(addt), ptr(out), ptr(ws), wsb, ptr(counters), counters.numel(),
-                                            ptr(part) if bn else None, ptr(pivd) if bn else None, N, H, W, cc, kk, relu, flip, stream()))
-
-    ref_lin = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=1).permute(0, 2, 3, 1)
-    sc = ref_lin.abs().max().item()
-    run(xd, wd, bd, None, y, C, K, 1, 0, False)
-    assert_close(y, torch.relu(ref_lin), rtol=1e-4, atol=1e-5 * sc, msg='staged 2-D Winograd forward + bias + ReLU')
-    y1 = y.clone()
-    run(xd, wd, bd, None, y, C, K, 1, 0, False)
-    assert torch.equal(y, y1), 'bitwise reproducible'
-    run(xd, wd, bd, addd, y, C, K, 0, 0, True)
-    ref2 = ref_lin + add
-    assert_close(y, ref2, rtol=1e-4, atol=1e-5 * sc, msg='staged 2-D Winograd forward + addend')
-    d = (ref2 - piv).reshape(-1, K).double()
-    s1, s2 = part[:, :, 0].double().sum(0).cpu(), part[:, :, 1].double().sum(0).cpu()
-    assert ((s1 - d.sum(0)).abs().max() / d.abs().sum(0).max()).item() < 1e-5
-    assert ((s2 - (d * d).sum(0)).abs().max() / (d * d).sum(0).max()).item() < 1e-5
-    assert int(counters.abs().sum()) == 0, 'tile counters back to zero'
-    if K % 8 == 0 and K >= 16:                                # the dgrad direction: dy has K channels
-        wt = w.permute(3, 1, 2, 0).contiguous()               # [C][R][S][K]
-        dx = torch.empty(N, H, W, C, device=DEV)
-        run(dy.to(DEV), wt.to(DEV), None, None, dx, K, C, 0, 1, False)
-        refdx = torch.nn.grad.conv2d_input((N, C, H, W), w.permute(0, 3, 1, 2).contiguous(), dy.permute(0, 3, 1, 2).contiguous(),
-                                           padding=1).permute(0, 2, 3, 1)
-        assert_close(dx, refdx, rtol=1e-4, atol=1e-5 * refdx.abs().max().item(), msg='staged 2-D Winograd dgrad filter')
-    if forced:
-        monkeypatch.delenv('NNL_WINO_PLAN_KS'); monkeypatch.delenv('NNL_WINO_PLAN_S')
-    lib.nnl_reload_env()
-
-
-def test_winograd_2d_staged_through_dispatcher_with_prepared_filter(monkeypatch):
-    """NNL_CONV_WINO=4 sends every legal 3x3 / stride 1 convolution of ops.conv2d to the staged 2-D kernel; forward + dgrad (+ the Winograd-
-    domain wgrad) of two stacked layers against torch CPU, once with the per-call filter transform and once with the filters prepared by
-    nnl_wino_filter_multi in the kernel's pre-tiled layout (ops.prepare_forward / prepare_backward): bitwise the same result."""
-    from neuralnetworklibrary_amd import ops
-    from neuralnetworklibrary_amd._lib import lib
-    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
-    monkeypatch.setenv('NNL_CONV_WINO', '4'); lib.nnl_reload_env()
-    try:
-        torch.manual_seed(3)
-        ref = torch.nn.Sequential(torch.nn.Conv2d(32, 80, 3, padding=1, bias=False), torch.nn.Conv2d(80, 48, 3, padding=1, bias=False))
-        x = torch.randn(4, 32, 18, 14)
-        xr = x.clone().requires_grad_(True)
-        yr = ref(xr); yr.square().sum().backward()
-        net = torch.nn.Sequential(HipConv2d(32, 80, 3, padding=1, bias=False), HipConv2d(80, 48, 3, padding=1, bias=False)).to(DEV)
-        with torch.no_grad():
-            for m, r in zip(net, ref):
-                m.weight.copy_(r.weight.to(DEV))
-        for gm in (ops._geom(4, 18, 14, 32, 80, 3, 3, 1, 1), ops._geom(4, 18, 14, 80, 48, 3, 3, 1, 1)):
-            assert lib.nnl_conv2d_wino_preferred(gm, 0) == 3 and lib.nnl_conv2d_wino_preferred(gm, 1) == 3
-        outs = []
-        for prepared in (False, True):
-            for m in net:
-                m.weight.grad = None
-            xd = x.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-            if prepared:
-                ops.prepare_forward(net)
-                assert len(ops._WINO_U_FWD) == 2, 'both filters prepared in the staged kernel\'s layout'
-            y = net(xd)
-            if prepared:
-                ops.prepare_backward(net)
-                assert len(ops._WINO_U_BWD) == 2
-            y.square().sum().backward()
-            ops.finish_backward()
-            outs.append((y.detach().clone(), xd.grad.clone(), net[0].weight.grad.clone(), net[1].weight.grad.clone()))
-        for a_, b_ in zip(outs[0], outs[1]):
-            assert torch.equal(a_, b_), 'prepared filter == per-call filter transform, bitwise'
-        y, dx, dw0, dw1 = outs[0]
-        assert_close(y, yr.detach(), rtol=1e-4, atol=1e-5 * yr.abs().max().item(), msg='forward')
-        assert_close(dx, xr.grad, rtol=1e-4, atol=1e-5 * xr.grad.abs().max().item(), msg='dgrad')
-        assert_close(dw0, ref[0].weight.grad, rtol=1e-4, atol=1e-5 * ref[0].weight.grad.abs().max().item(), msg='wgrad 0')
-        assert_close(dw1, ref[1].weight.grad, rtol=1e-4, atol=1e-5 * ref[1].weight.grad.abs().max().item(), msg='wgrad 1')
-    finally:
-        monkeypatch.delenv('NNL_CONV_WINO'); lib.nnl_reload_env()
-
-
 @pytest.mark.parametrize('case', [(2, 64, 12, 10, 64, None), (3, 32, 9, 7, 36, None), (4, 128, 14, 14, 128, (2, 4)), (1, 16, 2, 2, 8, None),
                                   (2, 64, 17, 33, 96, (1, 3))], ids=str)
 @pytest.mark.parametrize('chunk', ['0', '32'], ids=['position-major', 'chunk32'])
@@ -533,3 +429,41 @@ def _winograd_2d_debug_entry(case, chunk, pos, monkeypatch):
         monkeypatch.delenv('NNL_WINO_PLAN_KS'); monkeypatch.delenv('NNL_WINO_PLAN_S')
     monkeypatch.delenv('NNL_WINO2_CHUNK'); monkeypatch.delenv('NNL_WINO2_POS')
     lib.nnl_reload_env()
+
+
+def test_shared_parameters_fan_out_sums_the_per_call_gradients_in_one_launch():
+    """ops.shared_params (round 5): RetinaNet's head convolutions run on five pyramid levels; their weight / bias gradients used to be
+    summed by autograd's chain of accumulation kernels (91 ATen adds per step).  Inside the context every call takes an alias of the
+    parameter and one node adds the per-call gradients with ONE nnl_sum_tensors launch: same gradients (up to the order of the
+    additions), input gradients untouched, nothing left behind in the registry, and outside autograd the parameters are used directly."""
+    from neuralnetworklibrary_amd import ops
+    from neuralnetworklibrary_amd.Applications.VisionModels.retinanet import HipConv2d
+    torch.manual_seed(3)
+    conv = HipConv2d(32, 48, 3, padding=1, bias=True).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(2, 32, s, s, generator=g).to(DEV).requires_grad_(True) for s in (24, 12, 6, 3, 2)]
+
+    def run(fan):
+        conv.weight.grad = conv.bias.grad = None
+        for x in xs:
+            x.grad = None
+        if fan:
+            with ops.shared_params([conv], len(xs)):
+                outs = [conv(x) for x in xs]
+        else:
+            outs = [conv(x) for x in xs]
+        assert not ops._FAN
+        sum((o * o).sum() for o in outs).backward()
+        return conv.weight.grad.clone(), conv.bias.grad.clone(), [x.grad.clone() for x in xs]
+    w0, b0, x0 = run(False)
+    w1, b1, x1 = run(True)
+    w2, b2, _ = run(True)
+    assert torch.equal(w1, w2) and torch.equal(b1, b2), 'bitwise reproducible'
+    assert w1.stride() == conv.weight.stride()                      # the gradient keeps the parameter's KRSC layout
+    assert_close(w1, w0, rtol=1e-5, atol=1e-6 * w0.abs().max().item(), msg='weight gradient: one sum launch vs autograd accumulation')
+    assert_close(b1, b0, rtol=1e-5, atol=1e-6 * b0.abs().max().item(), msg='bias gradient')
+    for a, b in zip(x1, x0):
+        assert torch.equal(a, b), 'input gradients do not depend on the fan-out'
+    with torch.no_grad(), ops.shared_params([conv], 5):
+        assert not ops._FAN                                          # no autograd: nothing to fan out
+        assert_close(conv(xs[1]), conv(xs[1]), rtol=0, atol=0, msg='eval')

@@ -34,27 +34,23 @@ def test_predictions_finite_and_modes_consistent(lib):
     out = (C.c_double * 4)()
     seen = set()
     for N, H, C_, K in SHAPES:
-        os.environ.pop('NNL_CONV_WINO', None); os.environ.pop('NNL_CONV_WINO2', None); os.environ['NNL_CONV_WINO2S'] = '1'; lib.nnl_reload_env()
+        os.environ.pop('NNL_CONV_WINO', None); os.environ.pop('NNL_CONV_WINO2', None); lib.nnl_reload_env()
         mode = lib.nnl_debug_conv_plan_times(N, H, H, C_, K, out)
-        assert mode in (0, 1, 2, 3)
-        assert out[3] == -1.0 or 0.0 < out[3] < 1e7
+        assert mode in (0, 1, 2)
+        assert out[3] == -1.0                           # (the slot of round 4's spatially staged kernel: removed in round 5)
         assert all(0.0 < out[i] < 1e7 for i in range(3)), (N, H, C_, K, list(out))
         g = _geom(N, H, C_, K)
         assert lib.nnl_conv2d_wino_preferred(g, 0) == mode
         seen.add(mode)
-        if mode == 3:                                   # the spatially staged 2-D kernel: predicted under both the 1-D and the 2-D kernel
-            assert lib.nnl_conv2d_fwd_workspace_bytes(g) >= lib.nnl_debug_conv_wino2s_workspace_bytes(N, H, H, C_, K)
-            assert out[3] < 0.9 * (out[1] + 9.0 + 21.0 * C_ * K * 4.0 / 4.0e6) + 1e-9
-            os.environ['NNL_CONV_WINO2S'] = '0'; lib.nnl_reload_env()
-            assert lib.nnl_conv2d_wino_preferred(g, 0) in (1, 2)
-            os.environ['NNL_CONV_WINO2S'] = '1'
-        elif mode == 2:
+        t_d, t_w = out[0] + 6.0, out[1] + 9.0 + 21.0 * C_ * K * 4.0 / 4.0e6
+        if mode == 2:
             assert lib.nnl_conv2d_fwd_workspace_bytes(g) >= lib.nnl_debug_conv_wino2_workspace_bytes(N, H, H, C_, K)
-            assert out[2] < 0.9 * (out[1] + 9.0 + 21.0 * C_ * K * 4.0 / 4.0e6) + 1e-9        # the documented 10 % margin over the 1-D prediction
-            assert out[3] < 0 or out[3] > 1.1 * out[2]                    # (else the staged kernel would have been taken)
-            os.environ['NNL_CONV_WINO2'] = '0'; os.environ['NNL_CONV_WINO2S'] = '0'; lib.nnl_reload_env()
-            assert lib.nnl_conv2d_wino_preferred(g, 0) == 1
-            os.environ['NNL_CONV_WINO2S'] = '1'
+            # the documented 10 % margin: over the 1-D prediction where that beats the direct kernel, else (the position-split plan of
+            # the small grids, round 5) over the direct kernel's
+            assert out[2] < 0.9 * (t_w if t_w < 0.97 * t_d else t_d) + 1e-9
+            os.environ['NNL_CONV_WINO2'] = '0'; lib.nnl_reload_env()
+            assert lib.nnl_conv2d_wino_preferred(g, 0) == (1 if t_w < 0.97 * t_d else 0)
+            os.environ.pop('NNL_CONV_WINO2'); lib.nnl_reload_env()
         elif mode == 1:
             assert lib.nnl_conv2d_fwd_workspace_bytes(g) >= lib.nnl_debug_conv_wino_workspace_bytes(N, H, H, C_, K)
         os.environ['NNL_CONV_WINO'] = '0'; lib.nnl_reload_env()
@@ -64,26 +60,22 @@ def test_predictions_finite_and_modes_consistent(lib):
         os.environ['NNL_CONV_WINO'] = '3'; lib.nnl_reload_env()
         assert lib.nnl_conv2d_wino_preferred(g, 0) == (2 if H >= 2 else 1)
         assert lib.nnl_conv2d_fwd_workspace_bytes(g) >= lib.nnl_debug_conv_wino2_workspace_bytes(N, H, H, C_, K)
-        os.environ['NNL_CONV_WINO'] = '4'; lib.nnl_reload_env()
-        m4 = lib.nnl_conv2d_wino_preferred(g, 0)
-        assert m4 in (1, 2, 3) and (m4 == 3) == (H >= 7 and C_ % 8 == 0 and C_ >= 16)
-        if m4 == 3:
-            assert lib.nnl_conv2d_fwd_workspace_bytes(g) >= lib.nnl_debug_conv_wino2s_workspace_bytes(N, H, H, C_, K)
-    os.environ.pop('NNL_CONV_WINO2S', None); os.environ.pop('NNL_CONV_WINO', None); lib.nnl_reload_env()
-    assert seen >= {0, 1, 3}, 'the shape grid no longer reaches the direct, 1-D and staged 2-D kernels: %r' % (seen,)
+    os.environ.pop('NNL_CONV_WINO', None); lib.nnl_reload_env()
+    assert seen >= {0, 1, 2}, 'the shape grid no longer reaches the direct, 1-D and 2-D kernels: %r' % (seen,)
 
 
 def test_headline_and_small_batch_choices(lib):
-    """ResNet-34 at 64 images: every 3x3 stride-1 stage on the 2-D kernel (the spatially staged variant of round 4 is opt-in: it measured level
-    in the full step, profiles/r4_wino2s_step_ab.log; NNL_CONV_WINO2S=1 lets the planner take it); at 8 images the small stages stay on the
-    direct kernel (profiles/README.md: r3_wino2d_ab_bs64.log, r3_wino_bs8.log)."""
-    os.environ.pop('NNL_CONV_WINO', None); os.environ.pop('NNL_CONV_WINO2', None); os.environ.pop('NNL_CONV_WINO2S', None); lib.nnl_reload_env()
+    """ResNet-34 at 64 images: every 3x3 stride-1 stage on the 2-D kernel; at 8 images every stage is either on the direct kernel or on the 2-D
+    kernel's position-split plan (round 5: profiles/r5_wino2_pos_*.log) — never on a k-sliced 2-D plan or the 1-D kernel, which measured slower
+    there (profiles/README.md: r3_wino2d_ab_bs64.log, r3_wino_bs8.log)."""
+    os.environ.pop('NNL_CONV_WINO', None); os.environ.pop('NNL_CONV_WINO2', None); lib.nnl_reload_env()
     out = (C.c_double * 4)()
     assert [lib.nnl_debug_conv_plan_times(64, H, H, C_, C_, out) for C_, H in ((64, 56), (128, 28), (256, 14), (512, 7))] == [2, 2, 2, 2]
-    os.environ['NNL_CONV_WINO2S'] = '1'; lib.nnl_reload_env()
-    assert 3 in [lib.nnl_debug_conv_plan_times(64, H, H, C_, C_, out) for C_, H in ((64, 56), (128, 28), (256, 14), (512, 7))]
-    os.environ.pop('NNL_CONV_WINO2S'); lib.nnl_reload_env()
+    small = [lib.nnl_debug_conv_plan_times(8, H, H, C_, C_, out) for C_, H in ((128, 28), (256, 14), (512, 7))]
+    assert all(m in (0, 2) for m in small), small
+    os.environ['NNL_WINO2_POS'] = '0'; lib.nnl_reload_env()
     assert [lib.nnl_debug_conv_plan_times(8, H, H, C_, C_, out) for C_, H in ((128, 28), (256, 14), (512, 7))] == [0, 0, 0]
+    os.environ.pop('NNL_WINO2_POS'); lib.nnl_reload_env()
     # dgrad direction: geometry with K != C goes through the same rule with the roles swapped
     from neuralnetworklibrary_amd import ops
     g = ops._geom(64, 56, 56, 64, 128, 3, 3, 1, 1)

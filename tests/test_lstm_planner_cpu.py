@@ -1,4 +1,4 @@
-"""Host-only checks of the partition planners of the 2-D persistent recurrence kernels (csrc/lstm_bptt2.hip, csrc/lstm_fwd2.hip;
+"""Host-only checks of the partition planner of the 2-D persistent recurrence kernel (csrc/lstm_bptt2.hip;
 reference call site: WeightDropLSTM1.forward -> nn.LSTM, Applications/Text.py:495-513): whatever shape they accept, the partition
 must cover the problem, fit the launch limits the kernels assume (<= 256 co-resident workgroups, k slices in 16-wide groups,
 <= 6 column tiles) — no GPU needed: the debug entries only run the planner."""
@@ -27,25 +27,8 @@ def test_bptt2_partition_covers_the_problem(B, H):
     assert Ks * 16 * NT * 4 + 4 * 4 * NT * 64 * 4 <= 156 * 1024   # W block + hand-over buffers in LDS
 
 
-@pytest.mark.parametrize('B,H', SHAPES)
-def test_fwd2_partition_covers_the_problem(B, H):
-    out = (ctypes.c_int32 * 5)()
-    ok = lib.nnl_debug_lstm_fwd2_plan(B, H, out)
-    Kp = int(lib.nnl_lstm_padded_hidden(H))
-    if not ok:
-        pytest.skip('shape not taken by the 2-D forward kernel')
-    KG, NG, Ks, Us, NT = list(out)
-    assert 1 <= KG * NG <= 256
-    assert KG * Ks == Kp and Ks % 16 == 0
-    assert NG * Us >= H and (NG - 1) * Us < H
-    assert 1 <= NT <= 6 and 16 * NT >= 4 * Us                   # the four gate columns of a unit group fit the column tiles
-    assert (16 * Us + KG - 1) // KG <= 128
-
-
 def test_headline_shapes_are_taken_and_batches_over_64_are_not():
     out = (ctypes.c_int32 * 5)()
     for H in (1150, 400):                                       # the AWD-LSTM layers of BASELINE configs[3]
         assert lib.nnl_debug_lstm_bptt2_plan(64, H, out) == 1
-        assert lib.nnl_debug_lstm_fwd2_plan(64, H, out) == 1
     assert lib.nnl_debug_lstm_bptt2_plan(65, 1150, out) == 0     # four 16-row streams = 64 batch rows at most
-    assert lib.nnl_debug_lstm_fwd2_plan(65, 1150, out) == 0
