@@ -203,6 +203,10 @@ class _GraphedStep:
                 with torch.cuda.graph(graph, capture_error_mode='thread_local' if dp else 'global'):   # records; nothing executes until replay()
                     if dp:
                         gs.capture_begin()            # the replay counter's bump: the first node of the graph
+                    if dev.type == 'cuda':
+                        from .. import ops
+                        ops.prepare_forward(learner.model)   # all Winograd filters in ONE captured launch (the eager steps built the batch;
+                                                             # round 4 captured one filter-transform launch per convolution instead)
                     y_pred = learner.predict1minibatch(self.x)
                     self.loss = learner.loss_func(y_pred, self.y)
                     learner._backward(self.loss)

@@ -13,21 +13,22 @@
 
 namespace nnl_det {
 
-constexpr int kSortBlock = 256;
+constexpr int kSortBlock = 1024;      // 16 waves: 64 samples x 16 slices of the keys
 constexpr long kMaxSamples = 32768;      // above this the O(n^2) ranking stops paying for itself: callers keep the atomic kernels
 
-// One wave = 64 samples i (one per lane); the block's four waves split the n keys j between them and meet in LDS.  Every lane of a wave
+// One wave = 64 samples i (one per lane); the block's sixteen waves split the n keys j between them and meet in LDS.  Every lane of a wave
 // compares against the SAME key j, so the key stream is wave-uniform (scalar loads, four keys per iteration) — round 4's version gave
 // one thread a whole pass over all keys staged through an LDS tile: n / 256 workgroups (18 for the language model's 4480 tokens) of a
-// latency-bound loop, 213 us per step; this one runs n / 64 workgroups of n / 4 compares per lane.
+// latency-bound loop, 213 us per step; this one runs n / 64 workgroups of n / 16 compares per lane.
 static __global__ __launch_bounds__(kSortBlock) void rank_sort_kernel(const int64_t* __restrict__ idx, long stride, int n,
                                                                 int* __restrict__ order) {
-  __shared__ int part[4][64];
+  constexpr int NW = kSortBlock / 64;
+  __shared__ int part[NW][64];
   const int c = blockIdx.y, lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int i = blockIdx.x * 64 + lane;
   const int64_t ki = i < n ? idx[(long)i * stride + c] : 0;
-  const int per = (n + 3) / 4, j0 = w * per, j1 = min(j0 + per, n);
+  const int per = (n + NW - 1) / NW, j0 = min(w * per, n), j1 = min(j0 + per, n);
   const int64_t* kp = idx + c;
   int rank = 0;
   int j = j0;
@@ -42,7 +43,12 @@ static __global__ __launch_bounds__(kSortBlock) void rank_sort_kernel(const int6
   }
   part[w][lane] = rank;
   __syncthreads();
-  if (w == 0 && i < n) order[(long)c * n + part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]] = i;
+  if (w == 0 && i < n) {
+    int r = 0;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) r += part[q][lane];
+    order[(long)c * n + r] = i;
+  }
 }
 
 struct SegSumParams {

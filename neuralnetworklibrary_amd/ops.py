@@ -211,6 +211,7 @@ _WT_ACTIVE = {}       # weight data_ptr -> W^T tensor [C,R,S,K]; valid ONLY betw
 # layers that took the Winograd kernel at their LAST call (`_WINO_PREF`) in one launch each; the convolutions pick them up by weight
 # address.  The window closes in finish_backward() (Learner: in a `finally`), before the optimizer touches the weights.
 _WINO_U_FWD, _WINO_U_BWD = {}, {}     # (weight data_ptr, kernel mode) -> U [K,4|16,3|1,C] (forward) / U' [C,...,K] (dgrad) in that kernel's layout
+_WINO_GEN = [0]                       # training-step counter (prepare_forward): the recorded modes of a weight are those of its LAST step
 _WINO_PREF = {}                       # weight data_ptr -> [modes the forward calls took, modes the dgrad calls took] (sets; 1 = 1-D, 2 = 2-D kernel):
                                       # a weight shared between geometries (RetinaNet's heads: five pyramid levels) may need BOTH layouts
 
@@ -277,16 +278,22 @@ def _run_wino_batch(model, attr, items, out):
     out.update(batch.views)
 
 
+def _wino_modes(key_ptr, which):
+    e = _WINO_PREF.get(key_ptr)
+    return e[which][1] if e is not None else ()
+
+
 def prepare_forward(model):
     """Call right before the forward of a TRAINING step (Learner does): the Winograd filters of every HipConv2d whose last forward
     took the Winograd kernel, in one launch; valid until finish_backward()."""
     _WINO_U_FWD.clear()
+    _WINO_GEN[0] += 1                                    # a new training step: the modes recorded from here on replace the previous step's
     if os.environ.get('NNL_WINO_PREPARE', '1') == '0':
         return
     items = []
     for m in _conv_mods(model):
         w = m.weight
-        modes = _WINO_PREF.get(w.data_ptr(), ((), ()))[0]
+        modes = _wino_modes(w.data_ptr(), 0)
         if (modes and w.is_cuda and w.dim() == 4 and w.shape[2] == 3 and w.shape[3] == 3 and w.dtype == torch.float32
                 and w.is_contiguous(memory_format=torch.channels_last)):
             for mode in sorted(modes):
@@ -347,7 +354,7 @@ def prepare_backward(model):
     _WINO_U_BWD.clear()
     if os.environ.get('NNL_WINO_PREPARE', '1') != '0':
         items = [(w.data_ptr(), batch.views[w.data_ptr()], 1, mode) for w in ws if w.shape[2] == 3 and w.shape[3] == 3
-                 for mode in sorted(_WINO_PREF.get(w.data_ptr(), ((), ()))[1])]
+                 for mode in sorted(_wino_modes(w.data_ptr(), 1))]
         _run_wino_batch(model, '_nnl_wino_bwd_batch', items, _WINO_U_BWD)
 
 
@@ -368,10 +375,14 @@ def _wino_pref(key_ptr, which, g):
     per weight for the next step's batch (a weight shared between geometries keeps the mode of its LAST call; calls whose mode
     differs transform their own filter: the prepared buffer is only handed over when its size is that of the mode's layout)"""
     pref = int(lib.nnl_conv2d_wino_preferred(g, which)) if (g.R == 3 and g.S == 3 and g.stride == 1) else 0
-    if pref:
+    if pref or key_ptr in _WINO_PREF:
         if len(_WINO_PREF) > 8192:
             _WINO_PREF.clear()
-        _WINO_PREF.setdefault(key_ptr, [set(), set()])[which].add(pref)
+        e = _WINO_PREF.setdefault(key_ptr, [[-1, set()], [-1, set()]])[which]
+        if e[0] != _WINO_GEN[0]:                         # first call of this training step (prepare_forward opens a new one): forget the old modes
+            e[0], e[1] = _WINO_GEN[0], set()
+        if pref:
+            e[1].add(pref)
     return pref
 
 
