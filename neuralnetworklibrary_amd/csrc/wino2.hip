@@ -547,7 +547,9 @@ double w2_pos_cost(long T, long M4, int Nc, int C, int cs) {
   const long nb = nnl_cdiv(nwg, (long)kCUs);
   const double c = (double)(nb < occ ? nb : occ);
   const double slab_b = 2.0 * 16 * cs * (double)M4 * Nc * 4;
-  return nb * I * (b + a / c) + tfix * nb / c + slab_b / 11.7e6 + (3.0 + 1.5 * cs) + 10.0;
+  // (+ 4 us of launch: the filter pass is not charged — Learner's steps transform all filters in one batched launch, ops.prepare_forward;
+  // measured kernel-only at 8 images: 24.2 us against the direct kernel's 28.5, profiles/r5_wino2_pos_bs8_kernel_stats.csv)
+  return nb * I * (b + a / c) + tfix * nb / c + slab_b / 11.7e6 + (3.0 + 1.5 * cs) + 4.0;
 }
 
 // Cost of one schedule (us), fitted to 477 forced-schedule timings of this kernel (tools/wino2_plan_sweep.py, profiles/r3_wino2d_plan_sweep.log:

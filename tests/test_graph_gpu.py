@@ -122,6 +122,49 @@ def test_resnet_classifier_graph_replay_trains_like_eager():
     assert_close(lg, le, 1e-5, 1e-6, 'losses: graph replay vs eager')
 
 
+def test_resnet34_at_8_images_224_graph_replay_trains_like_eager():
+    """the strong-scaling regime — ResNet-34 + default head at 224 x 224 with 8 images per GPU (global batch 64 over 8
+    GPUs), where the dispatcher takes the small-grid plans (the position-split 2-D Winograd instantiation of round 5, k-sliced
+    direct tiles, Winograd-domain weight gradients on tiny grids) and the replayed step captures ONE batched filter-transform launch:
+    the replayed run must reproduce the eager run's losses (same kernels, same order), and the run with the position-split plan
+    switched off must agree with it to fp32 accuracy."""
+    from neuralnetworklibrary_amd.Applications import Vision as V
+    from neuralnetworklibrary_amd.General.Core import set_default_device
+    from neuralnetworklibrary_amd.General.Learner import Learner
+    from neuralnetworklibrary_amd._lib import lib
+    import os
+    set_default_device(DEV)
+    Learner.verbose = False
+    N, S = 8, 224
+    g = torch.Generator().manual_seed(6)
+    batches = [(torch.randn(N, 3, S, S, generator=g).to(DEV), torch.randint(0, 2, (N,), generator=g).to(DEV)) for _ in range(3)]
+
+    class D:
+        sz, categories, bs, target_type = (S, S), {0: 'a', 1: 'b'}, N, 'single_label'
+        train_dl = val_dl = batches
+
+    def run(graphs):
+        torch.manual_seed(0)
+        net = V.ImageClassificationNet(D, V.models.resnet34(), head=[[512], [0., 0.]])
+        learner = Learner('/tmp/nnl_graph_test', D, net, optimizer='SGD_Mom')
+        learner.init_optimizer(wd=1e-4)
+        if graphs:
+            learner.use_graphs(True, warmup=2)
+        net.train()
+        losses = [learner.train1minibatch(*batches[i % 3], [1e-4, 2e-4, 1e-3], mom_batch=0.9) for i in range(8)]
+        return np.array(losses), sum(gs.graph is not None for gs in learner._graphs.values())
+    le, _ = run(False)
+    lg, ng = run(True)
+    assert ng == 1
+    assert_close(lg, le, 1e-5, 1e-6, 'losses at 8 images: graph replay vs eager')
+    os.environ['NNL_WINO2_POS'] = '0'; lib.nnl_reload_env()
+    try:
+        l0, _ = run(False)
+    finally:
+        os.environ.pop('NNL_WINO2_POS'); lib.nnl_reload_env()
+    assert_close(le, l0, 1e-2, 1e-5, 'losses at 8 images: with / without the position-split 2-D Winograd plan')     # (training-mode BatchNorm at 8 images: two correct fp32 evaluations drift apart by ~1e-3 over 8 steps)
+
+
 def test_resnet_graph_replay_under_data_parallelism_matches_eager_dp():
     """Learner.use_graphs() with a GradSync attached: the captured forward + backward fills the all-reduce buckets (in-place
     wgrad writes and the hooks' copies are part of the graph), every replay is followed by the eager bucket all-reduces and the
