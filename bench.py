@@ -375,7 +375,7 @@ def measured_counters(args):
             d = os.path.join(base, tag)
             cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', d, '-o', tag, '--', 'python3', os.path.abspath(__file__),
                                                        '--steps', '3', '--warmup', '1', '--bs', str(args.bs), '--sz', str(args.sz), '--no-cpu-baseline', '--no-sweep',
-                                                       '--configs', 'none']
+                                                       '--no-counters', '--configs', 'none']
             r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=900)
             found = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
             if r.returncode != 0 or not found:
@@ -953,7 +953,8 @@ def worker(args):
                 out['configs'][name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
     if cpu:
         out['cpu_baseline'] = cpu_baseline_child('resnet', args.bs, args.sz)
-    if args.counters and world == 1 and rank == 0:
+    under_profiler = any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ) or 'rocprofiler' in os.environ.get('LD_PRELOAD', '')
+    if args.counters and world == 1 and rank == 0 and not under_profiler:       # (never from inside a profiler run: its children would nest)
         # the committed, stamp-gated figures stay the fallback; a measured pass of THIS build is reported beside them and fills the
         # two roofline fields when the committed ones are null (any source change since the passes were committed)
         mc = measured_counters(args)

@@ -4,11 +4,11 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r5p
 mkdir -p $O
-timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --configs none > $O/bench_under_rocprof.json.log 2>$O/rocprof_bench.err; echo "rocprof rc=$?"
+timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep --no-counters --configs none > $O/bench_under_rocprof.json.log 2>$O/rocprof_bench.err; echo "rocprof rc=$?"
 for f in $(find $O/prof_bench -name "*.db" | head -1); do python tools/stats_csv.py $f $O/bench_kernel_stats.csv; done
-timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none > /dev/null 2>$O/pmc_fetch.err; echo "pmc fetch rc=$?"
-timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none > /dev/null 2>$O/pmc_write.err; echo "pmc write rc=$?"
-timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o m -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --configs none > /dev/null 2>$O/pmc_mfma.err; echo "pmc mfma rc=$?"
+timeout -k 10 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --no-counters --configs none > /dev/null 2>$O/pmc_fetch.err; echo "pmc fetch rc=$?"
+timeout -k 10 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --no-counters --configs none > /dev/null 2>$O/pmc_write.err; echo "pmc write rc=$?"
+timeout -k 10 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o m -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sweep --no-counters --configs none > /dev/null 2>$O/pmc_mfma.err; echo "pmc mfma rc=$?"
 F=$(find $O/pmc_fetch -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "*counter_collection.csv" | head -1); M=$(find $O/pmc_mfma -name "*counter_collection.csv" | head -1)
 mkdir -p $O/profiles_out
 python - <<PY
