@@ -285,8 +285,9 @@ class RetinaNet(nn.Module):
         x3 = self.layer3(x2)
         x4 = self.layer4(x3)
         features = self.fpn([x2, x3, x4])
-        reg = torch.cat([self.regressionModel(f) for f in features], dim=1)
-        clas = torch.cat([self.classificationModel(f) for f in features], dim=1)
+        with ops.shared_params([self.regressionModel, self.classificationModel], len(features)):     # one gradient sum per shared parameter
+            reg = torch.cat([self.regressionModel(f) for f in features], dim=1)
+            clas = torch.cat([self.classificationModel(f) for f in features], dim=1)
         return [self.AnchorGenerator(img_batch), reg, clas]
 
 

@@ -203,6 +203,7 @@ def _pad_c4(t_nhwc):
 
 # ---- all filter transposes of a backward pass in one launch --------------------------------------------------------------
 _WT_ACTIVE = {}       # weight data_ptr -> W^T tensor [C,R,S,K]; valid ONLY between prepare_backward() and finish_backward()
+_WT_PADDED = {}       # (weight data_ptr, shape, pad) -> transposed, channel-padded filter of a K % 16 != 0 dgrad; same window
 
 
 # Prepared Winograd filters (include/nnl.h: nnl_wino_filter_multi).  The transformed filter of a 3x3 / stride 1 / pad 1 layer depends
@@ -366,6 +367,7 @@ def finish_backward():
 def _finish_backward_impl():
     "closes the window of everything prepare_forward / prepare_backward exposed (the optimizer is about to change the weights)"
     _WT_ACTIVE.clear()
+    _WT_PADDED.clear()
     _WINO_U_FWD.clear()
     _WINO_U_BWD.clear()
 
@@ -616,6 +618,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.set_materialize_grads(False)              # no zero-filled gradient tensor for `part` in backward
         ctx.g, ctx.relu, ctx.has_bias = g, relu, bias is not None
         ctx.c_in = x.shape[1]
+        ctx.w_layout = (tuple(weight.shape), tuple(weight.stride()))
         ctx.save_for_backward(xn, wn, y if relu else None)        # relu: 0 none, 1 ReLU, 2 sigmoid (both gates need the OUTPUT y)
         return from_nhwc(y), part
 
@@ -662,12 +665,18 @@ class _Conv2d(torch.autograd.Function):
                 # fall back to the first-generation kernel, ~2.5x slower); zero channels cost one copy of dy
                 padk = 16 - g.K % 16
                 dyn = torch.nn.functional.pad(dyn, (0, padk))
-                wn = torch.nn.functional.pad(wn, (0, 0, 0, 0, 0, 0, 0, padk))
+                wkey = (wn.data_ptr(), tuple(wn.shape), padk)
                 g = _geom(g.N, g.H, g.W, g.C, g.K + padk, g.R, g.S, g.stride, g.pad)
-            wt = _WT_ACTIVE.get(wn.data_ptr()) if g.K == K else None
+                wt = _WT_PADDED.get(wkey) if _WT_ACTIVE else None      # a shared filter (RetinaNet's output convs on five levels): padded + transposed ONCE per backward pass
+                if wt is None:
+                    wn = torch.nn.functional.pad(wn, (0, 0, 0, 0, 0, 0, 0, padk))
+            else:
+                wkey, wt = None, (_WT_ACTIVE.get(wn.data_ptr()) if g.K == K else None)
             if wt is None or tuple(wt.shape) != (g.C, g.R, g.S, g.K):
                 wt = torch.empty((g.C, g.R, g.S, g.K), dtype=torch.float32, device=dyn.device)
                 check(lib.nnl_conv2d_weight_transpose(ptr(wn), ptr(wt), g.K, g.R, g.S, g.C, stream()))
+                if wkey is not None and _WT_ACTIVE:                   # (only inside the prepare_backward .. finish_backward window: weights are fixed there)
+                    _WT_PADDED[wkey] = wt
             dxn = torch.empty((g.N, g.H, g.W, g.C), dtype=torch.float32, device=dyn.device)
             wsb = int(lib.nnl_conv2d_dgrad_workspace_bytes(g))
             dws = torch.empty(wsb // 4, dtype=torch.float32, device=dyn.device) if wsb else None
@@ -677,7 +686,7 @@ class _Conv2d(torch.autograd.Function):
             # stride 2: every output-parity class of a 3x3 / pad 1 filter has a tap, so every dx pixel passes through the epilogue
             fuse = shortcut is not None and g.K % 16 == 0 and shortcut.numel() == dxn.numel() \
                 and (g.stride == 1 or (g.stride == 2 and g.R == 3 and g.S == 3 and g.pad == 1))
-            wmode = _wino_pref(wn.data_ptr(), 1, g)
+            wmode = _wino_pref(wn.data_ptr() if g.K == K else 0, 1, g)      # (a channel-padded dgrad transforms its own filter: not recorded under the weight)
             u = _WINO_U_BWD.get((wn.data_ptr(), wmode)) if (wmode and g.K == K) else None
             if u is not None and u.numel() != _wino_u_numel(g.C, g.K, wmode):
                 u = None
@@ -710,6 +719,13 @@ class _Conv2d(torch.autograd.Function):
             else:
                 run_w()
                 dw = from_nhwc(dwn[:K, :, :, :ctx.c_in])
+                # a 1x1 filter's [K, C, 1, 1] gradient: give it EXACTLY the parameter's strides (the size-1 dimensions make them ambiguous);
+                # otherwise AccumulateGrad sees a layout mismatch and clones it into the parameter's layout — one device copy per 1x1
+                # convolution and step (53 of RetinaNet's 68 rocclr_copyBuffer launches, profiles/r5_retinanet_kernel_stats.csv)
+                wshape, wstride = getattr(ctx, 'w_layout', (None, None))
+                if (g.R == 1 and g.S == 1 and wshape == tuple(dw.shape) and wstride != tuple(dw.stride()) and dw.is_contiguous(memory_format=torch.channels_last)
+                        and wstride[1] == 1 and wstride[0] == dw.shape[1]):
+                    dw = dw.as_strided(wshape, wstride)
         if db_gated is not None:
             db = db_gated
         elif ctx.has_bias and ctx.needs_input_grad[2]:

@@ -66,7 +66,9 @@ class _LSTMRecurrence(torch.autograd.Function):
         check(lib.nnl_conv2d_weight_transpose(ptr(w_hh), ptr(w_t), G, 1, 1, Hw, stream()))
         if Gp != G:
             w_t = F.pad(w_t, (0, Gp - G))
-        dgates = torch.zeros(T, B, Gp, dtype=torch.float32, device=dev)        # pad columns must be zero
+        dgates = torch.empty(T, B, Gp, dtype=torch.float32, device=dev)
+        if Gp != G:
+            dgates[:, :, G:].zero_()                         # only the pad columns must be zero (round 4 zero-filled all 82 MB per layer)
         dh0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         dc0 = torch.empty(B, H, dtype=torch.float32, device=dev)
         wsb = int(lib.nnl_lstm_workspace_bytes(T, B, H))
@@ -78,9 +80,14 @@ class _LSTMRecurrence(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             # dW_hh[4H,H] = sum_t dgates_t^T h_{t-1}: the wgrad kernel on a 1x1 "conv" over T*B "pixels"
             Hp = _ceil4(H)
-            hprev = torch.cat([h0.view(1, B, H), y[:-1]], 0).view(T * B, H)
+            # h_{t-1} for t = 0 .. T-1, rows padded to Hp: ONE big strided copy (round 4: cat + pad = a copy, a fill and another copy)
+            hprev = torch.empty(T, B, Hp, dtype=torch.float32, device=dev)
+            hprev[0, :, :H] = h0
+            if T > 1:
+                hprev[1:, :, :H] = y[:-1]
             if Hp != H:
-                hprev = F.pad(hprev, (0, Hp - H))
+                hprev[:, :, H:].zero_()
+            hprev = hprev.view(T * B, Hp)
             g = _lib.ConvGeom(T * B, 1, 1, Hp, Gp, 1, 1, 1, 0, 1, 1)
             dwp = torch.empty(Gp, Hp, dtype=torch.float32, device=dev)
             wb = int(lib.nnl_conv2d_wgrad_workspace_bytes(g))

@@ -1,5 +1,5 @@
 import sys, os, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from torch.profiler import profile, ProfilerActivity
 dev = torch.device('cuda', 0)
