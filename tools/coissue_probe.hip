@@ -7,20 +7,44 @@
 #include <cstdio>
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NV, int KIND>
+template <int NV, int KIND, bool BF16 = false, int NOPS = 0>
 __global__ __launch_bounds__(512) void probe(float* out, int iters, float seed, unsigned mfma_mask, unsigned valu_mask) {
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   float s = 0.f;
   if ((mfma_mask >> wave) & 1) {
     f32x16 acc;
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float a = seed, b = -seed;
-    for (int it = 0; it < iters; ++it) {
+    if (BF16) {                                            // the bf16 matrix core: 16 dependent v_mfma_f32_32x32x16_bf16
+      bf16x8 a, b;
+      for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + e); b[e] = (__bf16)(seed - e); }
+      for (int it = 0; it < iters; ++it) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+      }
+    } else {
+      float a = seed, b = -seed;
+      float sv[4] = {seed, seed + 1.f, seed + 2.f, seed + 3.f};
+      for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+          // NOPS x 16 idle cycles of THIS wave behind each MFMA (64 cycles in the pipe): does the wave waiting at issue for its
+          // dependent MFMA hold the SIMD's issue port against the other wave?
+          if (NOPS < 0) {                                  // -NOPS independent v_fma_f32 of THIS wave behind each MFMA
+#pragma unroll
+            for (int q = 0; q < -NOPS; ++q) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(sv[q & 3]) : "v"(a), "v"(b));
+          }
+          if (NOPS >= 1) asm volatile("s_nop 15");
+          if (NOPS >= 2) asm volatile("s_nop 15");
+          if (NOPS >= 3) asm volatile("s_nop 15");
+          if (NOPS >= 4) asm volatile("s_nop 15");
+        }
+      }
     }
     for (int e = 0; e < 16; ++e) s += acc[e];
+    if (!BF16 && NOPS < 0) s += 1.f;
   } else if ((valu_mask >> wave) & 1) {
     if (KIND == 0) {                                       // v_pk_fma_f32
       f32x2 r[8];
@@ -53,13 +77,13 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, float seed, 
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
-template <int NV, int KIND>
+template <int NV, int KIND, bool BF16 = false, int NOPS = 0>
 float run(float* out, int iters, unsigned mm, unsigned vm) {
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  hipLaunchKernelGGL((probe<NV, KIND>), dim3(256), dim3(512), 0, 0, out, iters, 0.f, mm, vm);
+  hipLaunchKernelGGL((probe<NV, KIND, BF16, NOPS>), dim3(256), dim3(512), 0, 0, out, iters, 0.f, mm, vm);
   hipEventRecord(a);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe<NV, KIND>), dim3(256), dim3(512), 0, 0, out, iters, 0.f, mm, vm);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((probe<NV, KIND, BF16, NOPS>), dim3(256), dim3(512), 0, 0, out, iters, 0.f, mm, vm);
   hipEventRecord(b);
   hipEventSynchronize(b);
   float ms = 0;
@@ -87,6 +111,23 @@ int main() {
       if (kind == 2) { t[0] = run<32, 2>(out, iters, c.mm, c.vm); t[1] = run<64, 2>(out, iters, c.mm, c.vm); t[2] = run<128, 2>(out, iters, c.mm, c.vm); }
       printf("  %-68s  nv=32: %.3f us/iter   nv=64: %.3f   nv=128: %.3f\n", c.name, t[0], t[1], t[2]);
     }
+  }
+  printf("fp32 MFMA with n x s_nop 15 behind each (VALU kind v_fma_f32, 64 per iteration): [mfma on waves 0-3 only] / [+ valu on waves 4-7]\n");
+  printf("  n=0: %.3f / %.3f   n=1: %.3f / %.3f   n=2: %.3f / %.3f   n=3: %.3f / %.3f   n=4: %.3f / %.3f\n",
+         run<64, 1, false, 0>(out, iters, 0x0F, 0), run<64, 1, false, 0>(out, iters, 0x0F, 0xF0), run<64, 1, false, 1>(out, iters, 0x0F, 0),
+         run<64, 1, false, 1>(out, iters, 0x0F, 0xF0), run<64, 1, false, 2>(out, iters, 0x0F, 0), run<64, 1, false, 2>(out, iters, 0x0F, 0xF0),
+         run<64, 1, false, 3>(out, iters, 0x0F, 0), run<64, 1, false, 3>(out, iters, 0x0F, 0xF0), run<64, 1, false, 4>(out, iters, 0x0F, 0),
+         run<64, 1, false, 4>(out, iters, 0x0F, 0xF0));
+  printf("fp32 MFMA with n independent v_fma_f32 of the SAME wave behind each: [mfma on waves 0-3 only] / [+ 64 v_fma_f32 per iteration on waves 4-7]\n");
+  printf("  n=0: %.3f / %.3f   n=4: %.3f / %.3f   n=8: %.3f / %.3f   n=12: %.3f / %.3f   n=16: %.3f / %.3f\n",
+         run<64, 1, false, 0>(out, iters, 0x0F, 0), run<64, 1, false, 0>(out, iters, 0x0F, 0xF0), run<64, 1, false, -4>(out, iters, 0x0F, 0),
+         run<64, 1, false, -4>(out, iters, 0x0F, 0xF0), run<64, 1, false, -8>(out, iters, 0x0F, 0), run<64, 1, false, -8>(out, iters, 0x0F, 0xF0),
+         run<64, 1, false, -12>(out, iters, 0x0F, 0), run<64, 1, false, -12>(out, iters, 0x0F, 0xF0), run<64, 1, false, -16>(out, iters, 0x0F, 0),
+         run<64, 1, false, -16>(out, iters, 0x0F, 0xF0));
+  printf("MFMA kind: v_mfma_f32_32x32x16_bf16 (the bf16 matrix core), VALU kind v_fma_f32\n");
+  for (auto& c : cases) {
+    const float t0 = run<32, 1, true>(out, iters, c.mm, c.vm), t1 = run<64, 1, true>(out, iters, c.mm, c.vm), t2 = run<128, 1, true>(out, iters, c.mm, c.vm);
+    printf("  %-68s  nv=32: %.3f us/iter   nv=64: %.3f   nv=128: %.3f\n", c.name, t0, t1, t2);
   }
   return 0;
 }
