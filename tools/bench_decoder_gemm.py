@@ -43,3 +43,20 @@ for tile in ('-1', '0', '1', '2', '3'):
     td = timed(lambda: check(lib.nnl_conv2d_dgrad(ptr(dy), ptr(wt), ptr(dx), g, None, ptr(wd), wsd, ptr(cnt), stream())))
     fl = 2.0 * M * C * K / 1e9
     print('NNL_IGEMM_TILE=%s: fwd %.3f ms %.1f TF/s | dgrad %.3f ms %.1f TF/s' % (tile, tf, fl / tf, td, fl / td))
+
+# weight gradient dw[K, C] = dy^T x through the C ABI (the dispatcher's own tile; NNL_WGRAD_TILE needs the A/B build), and what the
+# vendor library (torch.mm -> hipBLASLt / rocBLAS) reaches on the same three products: the reference point for "how far is the tile loop
+# from a tuned fp32 GEMM on this part"
+os.environ.pop('NNL_IGEMM_TILE', None)
+lib.nnl_reload_env()
+dw = torch.empty(K, C, device=dev)
+wsw = int(lib.nnl_conv2d_wgrad_workspace_bytes(g)); ww = torch.empty(max(wsw // 4, 1), device=dev)
+tw = timed(lambda: check(lib.nnl_conv2d_wgrad(ptr(x), ptr(dy), ptr(dw), g, ptr(ww), wsw, stream())))
+fl = 2.0 * M * C * K / 1e9
+print('wgrad (default plan): %.3f ms %.1f TF/s' % (tw, fl / tw))
+ref = dy.t() @ x
+print('wgrad max |err| vs torch.mm: %.3g (of %.3g)' % ((dw - ref).abs().max().item(), ref.abs().max().item()))
+for name, fn in (('fwd   y = x w^T', lambda: torch.mm(x, w.t(), out=y)), ('dgrad dx = dy w', lambda: torch.mm(dy, w, out=dx)),
+                 ('wgrad dw = dy^T x', lambda: torch.mm(dy.t(), x, out=dw))):
+    t = timed(fn)
+    print('torch.mm %-18s %.3f ms %.1f TF/s' % (name, t, fl / t))

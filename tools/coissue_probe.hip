@@ -14,8 +14,8 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, float seed, 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   float s = 0.f;
   if ((mfma_mask >> wave) & 1) {
-    f32x16 acc;
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    f32x16 acc, acc2;
+    for (int e = 0; e < 16; ++e) { acc[e] = 0.f; acc2[e] = 0.f; }
     if (BF16) {                                            // the bf16 matrix core: 16 dependent v_mfma_f32_32x32x16_bf16
       bf16x8 a, b;
       for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(seed + e); b[e] = (__bf16)(seed - e); }
@@ -29,21 +29,22 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, float seed, 
       for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+          if (NOPS == 100 && (t & 1)) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);   // two independent chains
+          else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
           // NOPS x 16 idle cycles of THIS wave behind each MFMA (64 cycles in the pipe): does the wave waiting at issue for its
           // dependent MFMA hold the SIMD's issue port against the other wave?
           if (NOPS < 0) {                                  // -NOPS independent v_fma_f32 of THIS wave behind each MFMA
 #pragma unroll
             for (int q = 0; q < -NOPS; ++q) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(sv[q & 3]) : "v"(a), "v"(b));
           }
-          if (NOPS >= 1) asm volatile("s_nop 15");
-          if (NOPS >= 2) asm volatile("s_nop 15");
-          if (NOPS >= 3) asm volatile("s_nop 15");
-          if (NOPS >= 4) asm volatile("s_nop 15");
+          if (NOPS >= 1 && NOPS < 100) asm volatile("s_nop 15");
+          if (NOPS >= 2 && NOPS < 100) asm volatile("s_nop 15");
+          if (NOPS >= 3 && NOPS < 100) asm volatile("s_nop 15");
+          if (NOPS >= 4 && NOPS < 100) asm volatile("s_nop 15");
         }
       }
     }
-    for (int e = 0; e < 16; ++e) s += acc[e];
+    for (int e = 0; e < 16; ++e) s += acc[e] + acc2[e];
     if (!BF16 && NOPS < 0) s += 1.f;
   } else if ((valu_mask >> wave) & 1) {
     if (KIND == 0) {                                       // v_pk_fma_f32
@@ -124,6 +125,9 @@ int main() {
          run<64, 1, false, -4>(out, iters, 0x0F, 0xF0), run<64, 1, false, -8>(out, iters, 0x0F, 0), run<64, 1, false, -8>(out, iters, 0x0F, 0xF0),
          run<64, 1, false, -12>(out, iters, 0x0F, 0), run<64, 1, false, -12>(out, iters, 0x0F, 0xF0), run<64, 1, false, -16>(out, iters, 0x0F, 0),
          run<64, 1, false, -16>(out, iters, 0x0F, 0xF0));
+  printf("fp32 MFMA on TWO independent accumulators alternating: [mfma on waves 0-3 only] / [+ 64 v_fma_f32 per iteration on waves 4-7] / [+ 128]\n");
+  printf("  %.3f / %.3f / %.3f\n", run<64, 1, false, 100>(out, iters, 0x0F, 0), run<64, 1, false, 100>(out, iters, 0x0F, 0xF0),
+         run<128, 1, false, 100>(out, iters, 0x0F, 0xF0));
   printf("MFMA kind: v_mfma_f32_32x32x16_bf16 (the bf16 matrix core), VALU kind v_fma_f32\n");
   for (auto& c : cases) {
     const float t0 = run<32, 1, true>(out, iters, c.mm, c.vm), t1 = run<64, 1, true>(out, iters, c.mm, c.vm), t2 = run<128, 1, true>(out, iters, c.mm, c.vm);
