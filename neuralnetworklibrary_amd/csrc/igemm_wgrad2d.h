@@ -29,7 +29,11 @@ struct IgemmWgrad2dParams {
 template <int BT, int BK, bool PIPE, int KG>
 __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void igemm_wgrad2d_kernel(const IgemmWgrad2dParams p) {
   static_assert(KG == 1 || (size_t)KG * 2 * BK * (2 * BT) >= (size_t)BT * BT, "the staging LDS must hold one accumulator tile for the group reduction");
-  constexpr int CA = BT / 4, RA = 256 / CA, PA = BK / RA;
+  // staging map: a thread owns quad row(s) row0 + s * RA of the k tile and NCH = TWO 16-byte channel chunks of each (columns ca * 4 and
+  // ca * 4 + BT / 2), so the quad's pixel offsets and border masks are computed once for both: the fp32 MFMA does not overlap with VALU
+  // work on this part (tools/coissue_probe.hip), every address instruction of the k loop is paid in MFMA time
+  constexpr int NCH = (BK * BT / 8 >= 256) ? 2 : 1;        // (64 x 16 tile: one chunk per thread)
+  constexpr int CA = BT / (4 * NCH), RA = 256 / CA, PA = BK / RA, C2 = BT / 2;
   static_assert(PA >= 1 && BK % RA == 0, "tile/thread mapping");
   constexpr int WT = BT / 2, TM = WT / 32, TN = WT / 32;
   extern __shared__ __attribute__((aligned(16))) float lds_dyn[];
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
       r_j[s] = j; r_i[s] = i; a_off[s] = ao; b_off[s] = bo;
     }
   };
-  f32x4 ra[PA][4], rb[PA][4];
+  f32x4 ra[PA][NCH][4], rb[PA][NCH][4];
   auto load_tile = [&]() {
 #pragma unroll
     for (int s = 0; s < PA; ++s) {
@@ -108,16 +112,25 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
       const bool okA = ok && a_cok, h1 = i2 + 1 < p.H, w1 = j2 + 1 < p.W;
       const unsigned ao = (unsigned)a_off[s];
       // dy pixels with a zero coefficient are not fetched (wave-uniform selects)
-      ra[s][0] = buf_load4(ra_src, (a00 != 0.f && okA) ? ao : 0xFFFFFFFFu, 0);
-      ra[s][1] = buf_load4(ra_src, (a01 != 0.f && okA && w1) ? ao + (unsigned)a_px : 0xFFFFFFFFu, 0);
-      ra[s][2] = buf_load4(ra_src, (a10 != 0.f && okA && h1) ? ao + (unsigned)a_row : 0xFFFFFFFFu, 0);
-      ra[s][3] = buf_load4(ra_src, (a11 != 0.f && okA && h1 && w1) ? ao + (unsigned)(a_row + a_px) : 0xFFFFFFFFu, 0);
+      const unsigned a0 = (a00 != 0.f && okA) ? ao : 0xFFFFFFFFu, a1 = (a01 != 0.f && okA && w1) ? ao + (unsigned)a_px : 0xFFFFFFFFu;
+      const unsigned a2 = (a10 != 0.f && okA && h1) ? ao + (unsigned)a_row : 0xFFFFFFFFu;
+      const unsigned a3 = (a11 != 0.f && okA && h1 && w1) ? ao + (unsigned)(a_row + a_px) : 0xFFFFFFFFu;
       const bool ra_ok = (unsigned)(i2 - 1 + xi) < (unsigned)p.H, rb_ok = (unsigned)(i2 - 1 + rb_) < (unsigned)p.H;
       const bool ca_ok = (unsigned)(j2 - 1 + nu) < (unsigned)p.W, cb_ok = (unsigned)(j2 - 1 + cb_) < (unsigned)p.W;
-      rb[s][0] = buf_load4(rb_src, (ok && ra_ok && ca_ok) ? (unsigned)(b_off[s] + bd00) : 0xFFFFFFFFu, 0);
-      rb[s][1] = buf_load4(rb_src, (ok && ra_ok && cb_ok) ? (unsigned)(b_off[s] + bd01) : 0xFFFFFFFFu, 0);
-      rb[s][2] = buf_load4(rb_src, (ok && rb_ok && ca_ok) ? (unsigned)(b_off[s] + bd10) : 0xFFFFFFFFu, 0);
-      rb[s][3] = buf_load4(rb_src, (ok && rb_ok && cb_ok) ? (unsigned)(b_off[s] + bd11) : 0xFFFFFFFFu, 0);
+      const unsigned b0 = (ok && ra_ok && ca_ok) ? (unsigned)(b_off[s] + bd00) : 0xFFFFFFFFu;
+      const unsigned b1 = (ok && ra_ok && cb_ok) ? (unsigned)(b_off[s] + bd01) : 0xFFFFFFFFu;
+      const unsigned b2 = (ok && rb_ok && ca_ok) ? (unsigned)(b_off[s] + bd10) : 0xFFFFFFFFu;
+      const unsigned b3 = (ok && rb_ok && cb_ok) ? (unsigned)(b_off[s] + bd11) : 0xFFFFFFFFu;
+      // the second chunk of each pixel: the same (masked) offset + C2 floats in the scalar offset.  dy columns beyond Mc (a row tile that
+      // overhangs Mc) then read the neighbouring pixel's channels or 0 past the tensor: they only reach output rows >= Mc, never stored.
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        const unsigned so = (unsigned)(h * C2 * 4);
+        ra[s][h][0] = buf_load4(ra_src, a0, so); ra[s][h][1] = buf_load4(ra_src, a1, so);
+        ra[s][h][2] = buf_load4(ra_src, a2, so); ra[s][h][3] = buf_load4(ra_src, a3, so);
+        rb[s][h][0] = buf_load4(rb_src, b0, so); rb[s][h][1] = buf_load4(rb_src, b1, so);
+        rb[s][h][2] = buf_load4(rb_src, b2, so); rb[s][h][3] = buf_load4(rb_src, b3, so);
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -125,14 +138,18 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
     float* Bs = As + BK * BT;
 #pragma unroll
     for (int s = 0; s < PA; ++s) {
-      f32x4 va, vb;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {                   // coefficients 0 / +-1: exact sums
-        va[e] = __builtin_fmaf(a11, ra[s][3][e], __builtin_fmaf(a10, ra[s][2][e], __builtin_fmaf(a01, ra[s][1][e], a00 * ra[s][0][e])));
-        vb[e] = __builtin_fmaf(sr, __builtin_fmaf(sc, rb[s][3][e], rb[s][2][e]), __builtin_fmaf(sc, rb[s][1][e], rb[s][0][e]));
+      for (int h = 0; h < NCH; ++h) {
+        // coefficients 0 / +-1: exact sums.  a00 is 0 or 1 and an unfetched pixel reads as 0, so the first term needs no multiply
+        f32x4 va, vb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = __builtin_fmaf(a11, ra[s][h][3][e], __builtin_fmaf(a10, ra[s][h][2][e], __builtin_fmaf(a01, ra[s][h][1][e], ra[s][h][0][e])));
+          vb[e] = __builtin_fmaf(sr, __builtin_fmaf(sc, rb[s][h][3][e], rb[s][h][2][e]), __builtin_fmaf(sc, rb[s][h][1][e], rb[s][h][0][e]));
+        }
+        *reinterpret_cast<f32x4*>(As + (row0 + s * RA) * BT + h * C2 + ca * 4) = va;
+        *reinterpret_cast<f32x4*>(Bs + (row0 + s * RA) * BT + h * C2 + ca * 4) = vb;
       }
-      *reinterpret_cast<f32x4*>(As + (row0 + s * RA) * BT + ca * 4) = va;
-      *reinterpret_cast<f32x4*>(Bs + (row0 + s * RA) * BT + ca * 4) = vb;
     }
   };
 
