@@ -477,8 +477,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)
     }
     __syncthreads();
     NNL_TSTAMP(1);
-    int cur = 0;
-    for (int kt = 0; kt < nk; kt += 2) {
+    // pairs of k tiles, then the odd last one outside the loop: with an exit in the MIDDLE of the body (round 4) the compiler kept the
+    // accumulators of the two halves in different registers and copied all 32 of them (behind an MFMA drain) once per pair
+    int cur = 0, kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
       if (kt + 2 < nk) advance();
       load_tile2(c_nx);                          // tile kt+2 -> set B
       __builtin_amdgcn_sched_barrier(0);
@@ -487,15 +489,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 || (PF == 2 && BK == 32)
       store_tile(cur ^ 1);                       // set A = tile kt+1 (requested an iteration ago)
       __syncthreads();
       cur ^= 1;
-      if (kt + 1 >= nk) break;
       if (kt + 3 < nk) advance();
-      load_tile(c_nx, 0);                        // tile kt+3 -> set A
+      load_tile(c_nx, 0);                        // tile kt+3 -> set A (past the end: the last tile again, never used)
       __builtin_amdgcn_sched_barrier(0);
       compute(cur);
       __builtin_amdgcn_sched_barrier(0);
       store_tile2(cur ^ 1);                      // set B = tile kt+2
       __syncthreads();
       cur ^= 1;
+    }
+    if (kt < nk) {                               // odd count: the last tile sits in LDS[cur]
+      compute(cur);
+      __syncthreads();
     }
   } else {
   if (nk > 0) {

@@ -138,17 +138,40 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
     float* Bs = As + BK * BT;
 #pragma unroll
     for (int s = 0; s < PA; ++s) {
+      // coefficients 0 / +-1: exact sums.  a00 is 0 or 1 and an unfetched pixel reads as 0, so the first term needs no multiply; the terms
+      // of the pixels this position does not use are skipped by REAL wave-uniform branches (corner positions use one dy pixel, edges two,
+      // centre positions four: 1.25 of the 3 terms on average; the empty asm keeps the compiler from turning them into selects)
+      f32x4 va[NCH], vb[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) va[h] = ra[s][h][0];
+      if (a01 != 0.f) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < NCH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) va[h][e] = __builtin_fmaf(a01, ra[s][h][1][e], va[h][e]);
+      }
+      if (a10 != 0.f) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < NCH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) va[h][e] = __builtin_fmaf(a10, ra[s][h][2][e], va[h][e]);
+      }
+      if (a11 != 0.f) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int h = 0; h < NCH; ++h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) va[h][e] = __builtin_fmaf(a11, ra[s][h][3][e], va[h][e]);
+      }
 #pragma unroll
       for (int h = 0; h < NCH; ++h) {
-        // coefficients 0 / +-1: exact sums.  a00 is 0 or 1 and an unfetched pixel reads as 0, so the first term needs no multiply
-        f32x4 va, vb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          va[e] = __builtin_fmaf(a11, ra[s][h][3][e], __builtin_fmaf(a10, ra[s][h][2][e], __builtin_fmaf(a01, ra[s][h][1][e], ra[s][h][0][e])));
-          vb[e] = __builtin_fmaf(sr, __builtin_fmaf(sc, rb[s][h][3][e], rb[s][h][2][e]), __builtin_fmaf(sc, rb[s][h][1][e], rb[s][h][0][e]));
-        }
-        *reinterpret_cast<f32x4*>(As + (row0 + s * RA) * BT + h * C2 + ca * 4) = va;
-        *reinterpret_cast<f32x4*>(Bs + (row0 + s * RA) * BT + h * C2 + ca * 4) = vb;
+        for (int e = 0; e < 4; ++e)
+          vb[h][e] = __builtin_fmaf(sr, __builtin_fmaf(sc, rb[s][h][3][e], rb[s][h][2][e]), __builtin_fmaf(sc, rb[s][h][1][e], rb[s][h][0][e]));
+        *reinterpret_cast<f32x4*>(As + (row0 + s * RA) * BT + h * C2 + ca * 4) = va[h];
+        *reinterpret_cast<f32x4*>(Bs + (row0 + s * RA) * BT + h * C2 + ca * 4) = vb[h];
       }
     }
   };
