@@ -82,24 +82,27 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
   const int a_adv = adv_n * p.H * a_row + adv_i * 2 * a_row + adv_j * 2 * a_px, b_adv = adv_n * p.H * b_row + adv_i * 2 * b_row + adv_j * 2 * b_px;
   const int a_jwrap = 2 * a_row - p.W2 * 2 * a_px, b_jwrap = 2 * b_row - p.W2 * 2 * b_px;    // j -= W2, i += 1
   const int a_iwrap = p.H * a_row - p.H2 * 2 * a_row, b_iwrap = p.H * b_row - p.H2 * 2 * b_row;   // i -= H2, n += 1
+  // (r_i, r_j hold the quad's PIXEL row / column 2i, 2j: what the border tests below use)
   int r_k[PA], r_i[PA], r_j[PA], a_off[PA], b_off[PA];
 #pragma unroll
   for (int s = 0; s < PA; ++s) {
     const int k = k_begin + row0 + s * RA;
     const int n = k / HW2, rem = k - n * HW2;
-    r_k[s] = k; r_i[s] = rem / p.W2; r_j[s] = rem - r_i[s] * p.W2;
-    a_off[s] = ((n * p.H + 2 * r_i[s]) * p.W + 2 * r_j[s]) * a_px + a_col * 4;
-    b_off[s] = ((n * p.H + 2 * r_i[s] - 1) * p.W + 2 * r_j[s] - 1) * b_px + b_col * 4;      // may be negative: used only with a valid pixel delta
+    const int qi = rem / p.W2, qj = rem - qi * p.W2;
+    r_k[s] = k; r_i[s] = 2 * qi; r_j[s] = 2 * qj;
+    a_off[s] = ((n * p.H + 2 * qi) * p.W + 2 * qj) * a_px + a_col * 4;
+    b_off[s] = ((n * p.H + 2 * qi - 1) * p.W + 2 * qj - 1) * b_px + b_col * 4;      // may be negative: used only with a valid pixel delta
   }
+  const int adv_i2 = 2 * adv_i, adv_j2 = 2 * adv_j, W22 = 2 * p.W2, H22 = 2 * p.H2;
   auto advance = [&]() {
 #pragma unroll
     for (int s = 0; s < PA; ++s) {
       r_k[s] += BK;
-      int j = r_j[s] + adv_j, i = r_i[s] + adv_i, ao = a_off[s] + a_adv, bo = b_off[s] + b_adv;
-      const bool jw = j >= p.W2;
-      j -= jw ? p.W2 : 0; i += jw ? 1 : 0; ao += jw ? a_jwrap : 0; bo += jw ? b_jwrap : 0;
-      const bool iw = i >= p.H2;
-      i -= iw ? p.H2 : 0; ao += iw ? a_iwrap : 0; bo += iw ? b_iwrap : 0;
+      int j = r_j[s] + adv_j2, i = r_i[s] + adv_i2, ao = a_off[s] + a_adv, bo = b_off[s] + b_adv;
+      const bool jw = j >= W22;
+      j -= jw ? W22 : 0; i += jw ? 2 : 0; ao += jw ? a_jwrap : 0; bo += jw ? b_jwrap : 0;
+      const bool iw = i >= H22;
+      i -= iw ? H22 : 0; ao += iw ? a_iwrap : 0; bo += iw ? b_iwrap : 0;
       r_j[s] = j; r_i[s] = i; a_off[s] = ao; b_off[s] = bo;
     }
   };
@@ -108,13 +111,13 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
 #pragma unroll
     for (int s = 0; s < PA; ++s) {
       const bool ok = r_k[s] < k_end;
-      const int i2 = 2 * r_i[s], j2 = 2 * r_j[s];
-      const bool okA = ok && a_cok, h1 = i2 + 1 < p.H, w1 = j2 + 1 < p.W;
+      const int i2 = r_i[s], j2 = r_j[s];
+      const bool okA = ok && a_cok, h1 = i2 < p.H - 1, w1 = j2 < p.W - 1;
       const unsigned ao = (unsigned)a_off[s];
-      // dy pixels with a zero coefficient are not fetched (wave-uniform selects)
-      const unsigned a0 = (a00 != 0.f && okA) ? ao : 0xFFFFFFFFu, a1 = (a01 != 0.f && okA && w1) ? ao + (unsigned)a_px : 0xFFFFFFFFu;
-      const unsigned a2 = (a10 != 0.f && okA && h1) ? ao + (unsigned)a_row : 0xFFFFFFFFu;
-      const unsigned a3 = (a11 != 0.f && okA && h1 && w1) ? ao + (unsigned)(a_row + a_px) : 0xFFFFFFFFu;
+      // dy pixels with a zero coefficient are not fetched (wave-uniform selects); the pixel's byte delta rides in the scalar offset
+      const unsigned a0 = (a00 != 0.f && okA) ? ao : 0xFFFFFFFFu, a1 = (a01 != 0.f && okA && w1) ? ao : 0xFFFFFFFFu;
+      const unsigned a2 = (a10 != 0.f && okA && h1) ? ao : 0xFFFFFFFFu;
+      const unsigned a3 = (a11 != 0.f && okA && h1 && w1) ? ao : 0xFFFFFFFFu;
       const bool ra_ok = (unsigned)(i2 - 1 + xi) < (unsigned)p.H, rb_ok = (unsigned)(i2 - 1 + rb_) < (unsigned)p.H;
       const bool ca_ok = (unsigned)(j2 - 1 + nu) < (unsigned)p.W, cb_ok = (unsigned)(j2 - 1 + cb_) < (unsigned)p.W;
       const unsigned b0 = (ok && ra_ok && ca_ok) ? (unsigned)(b_off[s] + bd00) : 0xFFFFFFFFu;
@@ -126,8 +129,8 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : (BT >= 128 ? 2 : 3)) void ig
 #pragma unroll
       for (int h = 0; h < NCH; ++h) {
         const unsigned so = (unsigned)(h * C2 * 4);
-        ra[s][h][0] = buf_load4(ra_src, a0, so); ra[s][h][1] = buf_load4(ra_src, a1, so);
-        ra[s][h][2] = buf_load4(ra_src, a2, so); ra[s][h][3] = buf_load4(ra_src, a3, so);
+        ra[s][h][0] = buf_load4(ra_src, a0, so); ra[s][h][1] = buf_load4(ra_src, a1, so + (unsigned)a_px);
+        ra[s][h][2] = buf_load4(ra_src, a2, so + (unsigned)a_row); ra[s][h][3] = buf_load4(ra_src, a3, so + (unsigned)(a_row + a_px));
         rb[s][h][0] = buf_load4(rb_src, b0, so); rb[s][h][1] = buf_load4(rb_src, b1, so);
         rb[s][h][2] = buf_load4(rb_src, b2, so); rb[s][h][3] = buf_load4(rb_src, b3, so);
       }
