@@ -646,37 +646,39 @@ int launch_wgrad_v2(const float* dy, const float* x, float* out, long a_elems, l
   const int pipe = NNL_AB_INT("NNL_WGRAD_PIPE", 1);                 // A/B hook: 1 = software-pipelined fragment reads
   // staging LDS: 2 buffers x BK x (BM + BN) floats per wave group (dynamic: above 64 KB the kernel needs the attribute once)
   auto lds_bytes = [](int bm, int bn, int bk, int kg) { return (size_t)kg * 2 * bk * (bm + bn) * sizeof(float); };
-#define NNL_WGRAD_LAUNCH(BM_, BN_, BK_, PIPE_, KG_)                                                                              \
+#define NNL_WGRAD_LAUNCH(BM_, BN_, BK_, PIPE_, KG_, PAIR_)                                                                       \
   do {                                                                                                                           \
     const size_t lb = lds_bytes(BM_, BN_, BK_, KG_);                                                                             \
     if (lb > 64 * 1024) {                                                                                                        \
       static bool attr_set = false;                                                                                              \
       if (!attr_set) {                                                                                                           \
-        NNL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, PIPE_, KG_>),  \
+        NNL_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, PIPE_, KG_, false, PAIR_>),  \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));                                 \
         attr_set = true;                                                                                                         \
       }                                                                                                                          \
     }                                                                                                                            \
-    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, PIPE_, KG_>), grid, dim3(256 * KG_), lb, s, q);                  \
+    hipLaunchKernelGGL((igemm_wgrad_kernel<BM_, BN_, BK_, 2, 2, PIPE_, KG_, false, PAIR_>), grid, dim3(256 * KG_), lb, s, q);    \
   } while (0)
+  // PAIR staging (igemm_wgrad.h): both 16-byte chunks a thread stages per row must lie in one filter tap
+  const bool pair = (R * S == 1 || C % pl.bn == 0) && NNL_AB_INT("NNL_WGRAD_PAIR", 1) != 0;   // (A/B hook: 0 = the one-chunk staging everywhere)
   if (pl.bm == 128 && pl.bn == 128) {
-    if (pl.kg == 4) NNL_WGRAD_LAUNCH(128, 128, 16, true, 4);
-    else if (pl.kg == 2) NNL_WGRAD_LAUNCH(128, 128, 16, true, 2);
-    else if (pipe) NNL_WGRAD_LAUNCH(128, 128, 16, true, 1);
-    else NNL_WGRAD_LAUNCH(128, 128, 16, false, 1);                     // BK=32 measured -7 % here
+    if (pl.kg == 4) { if (pair) NNL_WGRAD_LAUNCH(128, 128, 16, true, 4, true); else NNL_WGRAD_LAUNCH(128, 128, 16, true, 4, false); }
+    else if (pl.kg == 2) NNL_WGRAD_LAUNCH(128, 128, 16, true, 2, false);
+    else if (pipe) { if (pair) NNL_WGRAD_LAUNCH(128, 128, 16, true, 1, true); else NNL_WGRAD_LAUNCH(128, 128, 16, true, 1, false); }
+    else NNL_WGRAD_LAUNCH(128, 128, 16, false, 1, false);              // BK=32 measured -7 % here
   } else if (pl.bm == 128) {
-    NNL_WGRAD_LAUNCH(128, 64, 16, false, 1);
+    NNL_WGRAD_LAUNCH(128, 64, 16, false, 1, false);
   } else if (pl.bn == 128) {
-    NNL_WGRAD_LAUNCH(64, 128, 16, true, 1);
+    NNL_WGRAD_LAUNCH(64, 128, 16, true, 1, false);
   } else {
     if (bk32 && pl.k_per_split % 32 == 0) {
-      if (pl.kg == 4) NNL_WGRAD_LAUNCH(64, 64, 32, true, 4);
-      else if (pl.kg == 2) NNL_WGRAD_LAUNCH(64, 64, 32, true, 2);
-      else if (pipe) NNL_WGRAD_LAUNCH(64, 64, 32, true, 1);
-      else NNL_WGRAD_LAUNCH(64, 64, 32, false, 1);
+      if (pl.kg == 4) { if (pair) NNL_WGRAD_LAUNCH(64, 64, 32, true, 4, true); else NNL_WGRAD_LAUNCH(64, 64, 32, true, 4, false); }
+      else if (pl.kg == 2) NNL_WGRAD_LAUNCH(64, 64, 32, true, 2, false);
+      else if (pipe) { if (pair) NNL_WGRAD_LAUNCH(64, 64, 32, true, 1, true); else NNL_WGRAD_LAUNCH(64, 64, 32, true, 1, false); }
+      else NNL_WGRAD_LAUNCH(64, 64, 32, false, 1, false);
     }
-    else if (pipe) NNL_WGRAD_LAUNCH(64, 64, 16, true, 1);
-    else NNL_WGRAD_LAUNCH(64, 64, 16, false, 1);
+    else if (pipe) NNL_WGRAD_LAUNCH(64, 64, 16, true, 1, false);
+    else NNL_WGRAD_LAUNCH(64, 64, 16, false, 1, false);
   }
 #undef NNL_WGRAD_LAUNCH
   NNL_CHECK_LAUNCH();

@@ -34,11 +34,18 @@ struct IgemmWgradParams {
 // Both transforms happen while the operand tiles are staged (two buffer loads and one add per element each); the reduction runs
 // over HALF as many rows against 12/9 as many columns: 1.5x fewer MFMA multiplies.  The slab reduce that follows folds dU back
 // to dW (dg0 = dU0 + (dU1 + dU2)/2, dg1 = (dU1 - dU2)/2, dg2 = (dU1 + dU2)/2 + dU3: wino_wgrad_finish_kernel, conv2d.hip).
-template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int KG = 1, bool WINO = false>
+// PAIR (round 5): a thread stages ONE pixel row and TWO 16-byte chunks of it per operand (columns c and c + BM / 2 resp. c + BN / 2, the
+// second through the load's scalar offset) instead of two rows and one chunk, so the per-step gather state (pixel index, (pp, qq) wraps,
+// border tests) is advanced once for both — on gfx950 that VALU work is paid in MFMA time (tools/coissue_probe.hip).  Legal when both
+// chunks of a column tile share one filter tap: 1x1 filters / linear layers, or C % BN == 0 (the launcher checks).  Columns beyond Mc / Nc
+// in the second chunk read a neighbouring pixel's channels (or 0 past the tensor): they only reach output rows / columns that are not stored.
+template <int BM, int BN, int BK, int WGM, int WGN, bool PIPE = false, int KG = 1, bool WINO = false, bool PAIR = false>
 __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 : 4)) void igemm_wgrad_kernel(const IgemmWgradParams p) {
   static_assert(WGM * WGN == 4, "4 waves per group");
   static_assert(KG == 1 || (size_t)KG * 2 * BK * (BM + BN) >= (size_t)BM * BN, "the staging LDS must hold one accumulator tile for the group reduction");
-  constexpr int CA = BM / 4, CB = BN / 4;
+  static_assert(!PAIR || (!WINO && BK * BM / 8 >= 256 && BK * BN / 8 >= 256), "PAIR: two chunks per thread on both operands");
+  constexpr int NCH = PAIR ? 2 : 1;
+  constexpr int CA = BM / (4 * NCH), CB = BN / (4 * NCH);
   constexpr int RA = 256 / CA, RB = 256 / CB;
   constexpr int PA = BK / RA, PB = BK / RB;
   static_assert(PA >= 1 && PB >= 1 && BK % RA == 0 && BK % RB == 0, "tile/thread mapping");
@@ -104,6 +111,7 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 
 
   f32x4 ra[PA], rb[PB];
   f32x4 ra2[WINO ? PA : 1], rb2[WINO ? PB : 1];                              // WINO: the second pixel of each pair
+  f32x4 rah[PAIR ? PA : 1], rbh[PAIR ? PB : 1];                              // PAIR: the second chunk of each row
   // Per-row gather state, advanced INCREMENTALLY by BK pixels per k tile (no division, multiplication or branch in the loop):
   // a pixel index k = (n, pp, qq) moves by BK = dn*P*Q + dp*Q + dq, with at most one carry out of qq and one out of pp; the
   // byte offset of its input pixel moves by a constant plus one constant per carry.  Row validity is two unsigned range
@@ -168,11 +176,17 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 
       return;
     }
 #pragma unroll
-    for (int i = 0; i < PA; ++i) ra[i] = buf_load4(ra_src, (a_cok && a_k[i] < k_end) ? a_off[i] : 0xFFFFFFFFu, 0);
+    for (int i = 0; i < PA; ++i) {
+      const unsigned o = (a_cok && a_k[i] < k_end) ? a_off[i] : 0xFFFFFFFFu;
+      ra[i] = buf_load4(ra_src, o, 0);
+      if constexpr (PAIR) rah[i] = buf_load4(ra_src, o, (unsigned)(BM / 2 * 4));
+    }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const bool ok = b_cok && b_k[i] < k_end && (unsigned)(b_pp[i] - pp_lo) < pp_span && (unsigned)(b_qq[i] - qq_lo) < qq_span;
-      rb[i] = buf_load4(rb_src, ok ? (unsigned)b_off[i] : 0xFFFFFFFFu, 0);
+      const unsigned o = ok ? (unsigned)b_off[i] : 0xFFFFFFFFu;
+      rb[i] = buf_load4(rb_src, o, 0);
+      if constexpr (PAIR) rbh[i] = buf_load4(rb_src, o, (unsigned)(BN / 2 * 4));
     }
   };
   auto store_tile = [&](int buf) {
@@ -196,9 +210,15 @@ __global__ __launch_bounds__(256 * KG, KG > 1 ? 1 : ((BM * BN >= 128 * 128) ? 3 
       return;
     }
 #pragma unroll
-    for (int i = 0; i < PA; ++i) *reinterpret_cast<f32x4*>(As + (ra_row + i * RA) * BM + ca * 4) = ra[i];
+    for (int i = 0; i < PA; ++i) {
+      *reinterpret_cast<f32x4*>(As + (ra_row + i * RA) * BM + ca * 4) = ra[i];
+      if constexpr (PAIR) *reinterpret_cast<f32x4*>(As + (ra_row + i * RA) * BM + BM / 2 + ca * 4) = rah[i];
+    }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) *reinterpret_cast<f32x4*>(Bs + (rb_row + i * RB) * BN + cb * 4) = rb[i];
+    for (int i = 0; i < PB; ++i) {
+      *reinterpret_cast<f32x4*>(Bs + (rb_row + i * RB) * BN + cb * 4) = rb[i];
+      if constexpr (PAIR) *reinterpret_cast<f32x4*>(Bs + (rb_row + i * RB) * BN + BN / 2 + cb * 4) = rbh[i];
+    }
   };
 
   f32x16 acc[TM][TN];
