@@ -20,6 +20,10 @@ done; fi
 if [ $SEC = conv2 ]; then for e in NNL_WINO_BALANCE=0 NNL_WINO2_POS=0 NNL_WINO2_POS=1 NNL_IGEMM_KTAIL=0; do
   run "$e" $CONV
 done; fi
+# after the round's last kernel changes (igemm_wgrad2d.h / igemm_wgrad.h staging): the weight-gradient switches once more
+if [ $SEC = wgrad ]; then for e in NNL_WGRAD_WINO2D=2 NNL_WGRAD_WINO2D=0 NNL_WGRAD_WINO=0; do
+  run "$e" tests/test_conv_gpu.py tests/test_vision_gpu.py
+done; fi
 if [ $SEC = lstm ]; then for e in NNL_LSTM_PERSIST=0 NNL_LSTM_PERSIST=1 NNL_LSTM_PERSIST=3 NNL_LSTM_FUSED_BWD=1; do
   run "$e" tests/test_text.py
 done; fi
