@@ -8,7 +8,7 @@ import sys
 
 def survey(path):
     txt = open(path).read().split('\n')
-    kernels, name = {}, None
+    kernels, name, rows = {}, None, []
     for i, l in enumerate(txt):
         m = re.match(r'^(_Z[\w]+):', l)
         if m:
@@ -38,11 +38,15 @@ def survey(path):
             # skip outer loops: another loop of this kernel lies strictly inside with the same MFMA count
             valu = sum(v for kk, v in c.items() if kk.startswith('v_') and 'mfma' not in kk)
             mov = sum(v for kk, v in c.items() if kk.startswith('v_mov') or kk.startswith('v_accvgpr'))
+            rows.append({'kernel': k, 'loop': h, 'mfma': n_m, 'valu': valu, 'mov': mov, 's_nop': c['s_nop'],
+                         'lds': sum(v for kk, v in c.items() if kk.startswith('ds_')),
+                         'vmem': sum(v for kk, v in c.items() if kk.startswith('buffer_') or kk.startswith('global_'))})
+    return rows
+
+
+if __name__ == '__main__':
+    for f in sys.argv[1:]:
+        print(f)
+        for r in survey(f):
             print('  %-10s mfma %3d  VALU %4d (mov %3d)  s_nop %2d  lds %3d  vmem %3d  %s' % (
-                h, n_m, valu, mov, c['s_nop'], sum(v for kk, v in c.items() if kk.startswith('ds_')),
-                sum(v for kk, v in c.items() if kk.startswith('buffer_') or kk.startswith('global_')), k[:110]))
-
-
-for f in sys.argv[1:]:
-    print(f)
-    survey(f)
+                r['loop'], r['mfma'], r['valu'], r['mov'], r['s_nop'], r['lds'], r['vmem'], r['kernel'][:110]))
